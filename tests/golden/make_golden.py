@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ (run in the build container; output committed).
+
+Independent source of truth: scikit-learn 1.7.2 -- the library the reference's own known-answer
+constants were produced with (matern_kernel.rs:203,210; product_kernel.rs:139,146 say "produced by
+sklearn").  For every BASELINE config at a reduced n we store {X, y, theta} -> {lml, grad[p], alpha,
+K samples, mean, var} computed by sklearn's ConstantKernel*Matern+WhiteKernel GP, re-ordered to the
+reference's theta order [noise, amplitude, ell...] (lml.rs:67-68) and with the reference's predictive
+variance convention (no sigma^2, +1e-5, predict.rs:25-37).
+
+Also writes reference_kats.json: the numeric tables of the reference's own unit tests (data only).
+Usage: python tests/golden/make_golden.py
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+from scipy.linalg import solve_triangular
+from sklearn.gaussian_process import GaussianProcessRegressor
+from sklearn.gaussian_process.kernels import ConstantKernel, Matern, WhiteKernel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from hbetune_rs_amd import synth  # noqa: E402
+
+CASES = [
+    # (fixture name, config, n, nu, m candidates)
+    ("c1_sphere_n64_nu25", "C1", 64, 2.5, 32),
+    ("c1_sphere_n64_nu15", "C1", 64, 1.5, 32),
+    ("c1_sphere_n64_nu05", "C1", 64, 0.5, 32),
+    ("c2_rosenbrock_n192", "C2", 192, 2.5, 48),
+    ("c3_rastrigin_n160", "C3", 160, 2.5, 40),
+    ("c4_goldstein_n256", "C4", 256, 2.5, 64),
+    ("c5_himmelblau_n128", "C5", 128, 2.5, 32),
+    ("m_rosenbrock_n256", "M", 256, 2.5, 64),
+    ("m_rosenbrock_n100_ragged", "M", 100, 2.5, 7),
+]
+
+
+def sk_case(name, cfg, n, nu, m):
+    w = synth.make_workload(cfg, n=n, dtype="float64")
+    X, y, theta = w["X"], w["y"], w["theta"]
+    d = w["d"]
+    s2, c = math.exp(theta[0]), math.exp(theta[1])
+    ell = np.exp(theta[2:])
+    kernel = ConstantKernel(c) * Matern(length_scale=ell, nu=nu) + WhiteKernel(s2)
+    gp = GaussianProcessRegressor(kernel=kernel, alpha=0.0, optimizer=None, normalize_y=False).fit(X, y)
+    sk_theta = gp.kernel_.theta  # [ln c, ln ell..., ln s2]
+    lml, g = gp.log_marginal_likelihood(sk_theta, eval_gradient=True)
+    grad = np.concatenate([[g[-1]], g[:-1]])  # -> [noise, c, ell...]
+    K = gp.kernel_(X)
+    Xs = synth.candidates(cfg, m, d)
+    k_trans = gp.kernel_.k1(Xs, X)  # c * Matern, no white noise
+    mean = k_trans @ gp.alpha_
+    V = solve_triangular(gp.L_, k_trans.T, lower=True)
+    var = c + 1e-5 - (V * V).sum(axis=0)
+    var = np.where(var < 0, 0.0, var)
+    cond = np.linalg.cond(K)
+    out = dict(
+        X=X, y=y, theta=theta, nu=np.float64(nu), Xs=Xs,
+        lml=np.float64(lml), grad=grad, alpha=gp.alpha_,
+        K_rows=K[:4].copy(), K_diag=np.diag(K).copy(), K_sum=np.float64(K.sum()),
+        mean=mean, var=var, cond=np.float64(cond),
+        lo=w["lo"], hi=w["hi"],
+    )
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: n={n} d={d} nu={nu} lml={lml:.6f} |grad|max={np.abs(grad).max():.3e} cond(K)={cond:.2e}")
+
+
+# Numeric tables of the reference's own unit tests (data, no code).
+REFERENCE_KATS = {
+    "matern_nu15": {  # matern_kernel.rs:189-220
+        "source": "src/gpr/matern_kernel.rs:200-214", "nu": 1.5, "amplitude": 1.0, "length_scale": [1.0, 1.0],
+        "x": [[0.0, 0.0], [1.0, 1.0], [1.0, 2.0]], "tol": 1e-3,
+        "kernel": [[1.0, 0.29782077, 0.1013397], [0.29782077, 1.0, 0.48335772], [0.1013397, 0.48335772, 1.0]],
+        "gradient": [
+            [[0.0, 0.0], [0.25901289, 0.25901289], [0.0623887, 0.24955481]],
+            [[0.25901289, 0.25901289], [0.0, 0.0], [0.0, 0.53076362]],
+            [[0.0623887, 0.24955481], [0.0, 0.53076362], [0.0, 0.0]],
+        ],
+    },
+    "matern_nu25": {  # matern_kernel.rs:222-253
+        "source": "src/gpr/matern_kernel.rs:233-247", "nu": 2.5, "amplitude": 1.0, "length_scale": [1.0, 1.0],
+        "x": [[0.0, 0.0], [1.0, 1.0], [1.0, 2.0]], "tol": 1e-3,
+        "kernel": [[1.0, 0.31728336, 0.09657724], [0.31728336, 1.0, 0.52399411], [0.09657724, 0.52399411, 1.0]],
+        "gradient": [
+            [[0.0, 0.0], [0.29364328, 0.29364328], [0.06737947, 0.26951788]],
+            [[0.29364328, 0.29364328], [0.0, 0.0], [0.0, 0.57644039]],
+            [[0.06737947, 0.26951788], [0.0, 0.57644039], [0.0, 0.0]],
+        ],
+    },
+    "product_const_matern25": {  # product_kernel.rs:120-169 ; gradient last axis = [amplitude, ell_1, ell_2]
+        "source": "src/gpr/product_kernel.rs:137-163", "nu": 2.5, "amplitude": 2.0, "length_scale": [1.0, 1.0],
+        "x": [[0.5, 7.8], [3.3, 1.4], [3.9, 5.6]], "tol": 1e-3,
+        "kernel": [
+            [2.0, 3.22221679e-05, 8.73105609e-03],
+            [3.22221679e-05, 2.0, 6.14136045e-03],
+            [8.73105609e-03, 6.14136045e-03, 2.0],
+        ],
+        "gradient": [
+            [[2.0, 0.0, 0.0], [3.22221679e-05, 7.14401245e-05, 3.73238201e-04], [8.73105609e-03, 4.52409267e-02, 1.89417029e-02]],
+            [[3.22221679e-05, 7.14401245e-05, 3.73238201e-04], [2.0, 0.0, 0.0], [6.14136045e-03, 9.54435058e-04, 4.67673178e-02]],
+            [[8.73105609e-03, 4.52409267e-02, 1.89417029e-02], [6.14136045e-03, 9.54435058e-04, 4.67673178e-02], [2.0, 0.0, 0.0]],
+        ],
+    },
+    "cdist": [  # matern_kernel.rs:285-305 (exact)
+        {"a": [[1.0, 3.0]], "b": [[2.0, 5.0]], "sq": [[5.0]]},
+        {"a": [[0.0, 0.0], [1.0, 1.0], [2.0, 2.0]], "b": [[1.0, 2.0], [3.0, 4.0]], "sq": [[5.0, 25.0], [1.0, 13.0], [1.0, 5.0]]},
+    ],
+    "simple_fit": {  # predict.rs:54-99
+        "source": "src/gpr/predict.rs:60-98", "xs": [[0.0], [0.5], [0.5], [1.0]], "ys": [0.0, 0.8, 1.2, 2.0],
+        "amplitude": [3.0, 0.1, 4.0], "length_scale": [[1.5, 0.1, 2.0]], "noise": [1.0, 0.001, 1.0],
+        "nu": 2.5, "n_restarts": 4, "predict_xs": [[0.0], [0.25], [0.5], [0.75], [1.0]],
+        "mean": [0.0, 0.5, 1.0, 1.5, 2.0], "mean_tol": 0.1, "var": 0.03, "var_tol": 0.03,
+    },
+    "clamp": [  # predict.rs:129-149
+        {"variances": [1.0, -2.0, -0.5], "level": -1.0, "below": [-2.0], "after": [1.0, 0.0, 0.0]},
+        {"variances": [1.0, 2.0, -0.5], "level": -1.0, "below": [], "after": [1.0, 2.0, 0.0]},
+    ],
+    "slanted_plane": {  # gradmin.rs:62-101
+        "source": "src/util/gradmin.rs:75-101", "start": [0.0, 0.0], "bounds": [[-2.0, 2.0], [-2.0, 2.0]],
+        "x": [-2.0, -2.0], "f": -4.0,
+    },
+}
+
+if __name__ == "__main__":
+    for case in CASES:
+        sk_case(*case)
+    with open(os.path.join(HERE, "reference_kats.json"), "w") as f:
+        json.dump(REFERENCE_KATS, f, indent=1)
+    print("wrote", len(CASES), "npz fixtures + reference_kats.json")
