@@ -1,0 +1,26 @@
+# Builds libhbegp.so (HIP kernels + host runtime + C ABI) for gfx950, in-tree.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CXXFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result
+LIB = hbetune_rs_amd/libhbegp.so
+SRC = csrc/kernels.hip csrc/hbegp.cpp
+HDR = csrc/engine.hpp csrc/lbfgsb.hpp include/hbegp.h
+
+all: $(LIB)
+
+build/kernels.o: csrc/kernels.hip $(HDR)
+	@mkdir -p build
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+build/hbegp.o: csrc/hbegp.cpp $(HDR)
+	@mkdir -p build
+	$(HIPCC) -O3 -std=c++17 -fPIC -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -x c++ -c $< -o $@
+$(LIB): build/kernels.o build/hbegp.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
+
+oracle: oracle/libgpr_oracle.so
+oracle/libgpr_oracle.so: oracle/gpr_oracle.c
+	gcc -O2 -fPIC -shared -o $@ $< -lm
+
+clean:
+	rm -rf build $(LIB) oracle/libgpr_oracle.so
+.PHONY: all clean oracle

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — GP fit+predict throughput of the MI355X engine on BASELINE.json's metric configuration.
+
+One "step" = one fixed-work fit + one batched predict on config M (rosenbrock d=8, n=4096, f64):
+  * fit: (1 + R) = 3 bounded L-BFGS runs x 150 log-marginal-likelihood+gradient evaluations (the reference's cap:
+    gpr.rs:222 n_restarts_optimizer = 2, gradmin.rs:54 maxeval = 150), K^-1 of the captured best evaluation,
+  * predict: mean + variance at m = 1600 candidates (about one generation of the caller's predict calls).
+Inputs are synthetic (hbetune_rs_amd/synth.py), uploaded to HBM inside the C ABI call; the timed region covers the
+whole fit+predict call chain (H2D of X, y is ~300 KB and included).
+
+Multi-GPU: the path shards as independent units with no exchange step: every rank runs whole
+fit+predict steps on its own GPU ("weak" scaling, no data-path collective); torch.distributed (RCCL) is only used
+for the barrier and the max-over-ranks of the timings.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor); measured 77.1 with tools/ubench.hip
+EVALS_PER_RUN = 150
+N_RESTARTS = 2
+M_CANDIDATES = 1600
+
+
+def cpu_baseline(w, theta, Xs):
+    """Reference-faithful CPU port (oracle/gpr_oracle.py: materialised dK tensor, LAPACK potrf/potrs/potri), 1 thread
+    (the reference builds OpenBLAS with USE_THREAD=0, Makefile:3-4).  Bounded sample: ONE evaluation + one predict."""
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+
+    from oracle import gpr_oracle as O
+
+    s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        res = O.lml_with_gradient(w["X"], w["y"], s2, c, ell, 2.5)
+        t_eval = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.predict(Xs, w["X"], res["alpha"], res["k_inv"], c, ell, 2.5)
+        t_pred = time.perf_counter() - t0
+    n_evals = (1 + N_RESTARTS) * EVALS_PER_RUN
+    fit_predict_s = n_evals * t_eval + t_pred
+    return {
+        "value": 1.0 / fit_predict_s,
+        "unit": "fit+predict/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"1 lml+gradient evaluation ({t_eval:.2f} s, x{n_evals} per fit) + 1 predict m={len(Xs)} ({t_pred:.2f} s), "
+                  f"n={w['n']} d={w['d']} f64, numpy + LAPACK dpotrf/dpotrs/dpotri, 1 thread",
+        "eval_s": t_eval,
+        "predict_s": t_pred,
+    }, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=None, help="override n (debug only; invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import numpy as np
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from hbetune_rs_amd import gpr, synth
+
+    w = synth.make_workload("M", n=args.n)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    n, d = X.shape
+    starts = synth.restart_points("M", w["lo"], w["hi"], N_RESTARTS)
+    Xs = synth.candidates("M", M_CANDIDATES, d)
+
+    ctx = gpr.Context(device_ids=[local_rank])
+
+    def step():
+        fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, nu=2.5, ctx=ctx, maxeval=EVALS_PER_RUN,
+                                  fixed_work=True)
+        mean, var, _ = fk.predict(Xs)
+        fk.release()
+        return mean, var
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed  # whole-job fit+predict per second
+        # roofline of the dominant kernel (gemm_kernel<double,128>: Cholesky/TRTRI/LAUUM tile GEMMs), measured live with
+        # hipEvents on the evaluation stream: algorithmic GFLOP of its launches in one evaluation / their summed duration.
+        prob = gpr.Problem(X, y, nu=2.5, ctx=ctx)
+        ph = prob.time_eval(theta, reps=5)
+        big = "gemm128" if ph["gemm128_ms"] > 0 else "gemm64"
+        achieved = ph[f"{big}_gflop"] / ph[f"{big}_ms"] if ph[f"{big}_ms"] > 0 else 0.0  # GFLOP/ms = TFLOP/s
+        eval_tflops = (n ** 3) * 1e-12 / (ph["eval_graph_ms"] * 1e-3)
+        roofline = {
+            "bound": "mfma",
+            "kernel": f"hbegp::gemm_kernel<double,{big[4:]}>",
+            "achieved": achieved,
+            "peak": PEAK_FP64_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            "traffic": None,
+            "algorithmic_gflop_per_eval": ph[f"{big}_gflop"],
+            "kernel_ms_per_eval": ph[f"{big}_ms"],
+            "whole_eval_ms": ph["eval_graph_ms"],
+            "whole_eval_frac_of_peak": eval_tflops / PEAK_FP64_MFMA_TFLOPS,
+            "whole_fit_frac_of_peak": ((1 + N_RESTARTS) * EVALS_PER_RUN * n ** 3 + 2.0 * M_CANDIDATES * n * n) * 1e-12
+                                      / (ms_per_step * 1e-3) / PEAK_FP64_MFMA_TFLOPS,
+            "phases_ms": {k: round(v, 4) for k, v in ph.items()},
+        }
+        prob.close()
+        out = {
+            "metric": "GP fit+predict/sec (n=4096,d=8,f64)",
+            "value": value,
+            "unit": "fit+predict/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"M: rosenbrock d={d} n={n} f64, Matern nu=5/2 x constant + white noise; fixed-work fit = "
+                            f"{1 + N_RESTARTS} L-BFGS runs x {EVALS_PER_RUN} lml+gradient evaluations + K^-1, then predict "
+                            f"mean+variance at m={M_CANDIDATES}",
+                "evals_per_fit": (1 + N_RESTARTS) * EVALS_PER_RUN,
+                "m_candidates": M_CANDIDATES,
+                "parallelism": f"replicas x{world} (independent fits per GPU, no collective)",
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref = cpu_baseline(w, theta, Xs)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_port"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+// engine.hpp — device-side engine interface shared by kernels.hip (HIP kernels + launchers) and
+// hbegp.cpp (host runtime, C ABI).  Everything here is plain C++; no torch, no oracle.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace hbegp {
+
+constexpr int NB = 128;     // leaf (diagonal block) size; all matrices are padded to a multiple of NB
+constexpr int MAXD = 64;    // max number of features
+constexpr int MAXP = MAXD + 2;
+
+// Per-evaluation hyper-parameters, linear space, already clamped (fit.rs:94-96).  Lives in device memory;
+// the host refreshes it with one hipMemcpyAsync before each evaluation so captured graphs stay valid.
+struct EvalParams {
+  double noise;      // sigma^2
+  double amp;        // c
+  double ell[MAXD];  // length scales
+};
+
+// Per-evaluation scalar results (device -> pinned host).
+struct EvalOut {
+  double lml;
+  double yalpha;   // y^T alpha
+  double logdet;   // sum_i log L_ii
+  double grad[MAXP];
+  int info;        // 0 ok, else 1 + index of the failing pivot (not positive definite)
+  int n_warn;      // predict: variances below -sqrt(1e-5)
+};
+
+// One tile-GEMM operation on row-major matrices, in units of TILE x TILE tiles (global tile coordinates).
+//   C(ti,tj) = beta*C(ti,tj) + alpha * sum_{tk in range(ti,tj)} opA(ti,tk) * opB(tk,tj)
+// a_kmajor = 0: A tile (ti,tk) is read from A[ti*T.., tk*T..] (rows = output rows, contraction along columns)
+// a_kmajor = 1: A tile is read from A[tk*T.., ti*T..] (rows = contraction index)        (same for B with tj)
+struct GemmOp {
+  const void* A;
+  const void* B;
+  void* C;
+  int lda, ldb, ldc;
+  int a_kmajor, b_kmajor;
+  int ci0, cj0;   // first output tile (row, col)
+  int mi, nj;     // output tiles (rows, cols)
+  int c_lower;    // only tiles with global ti >= tj
+  int k0, k1;     // contraction tile range [k0, k1)
+  int klim;       // 0 none | 1: k <= tj | 2: k >= tj | 3: k <= ti | 4: k >= ti   (global tile coordinates)
+  int maskA, maskB;  // on storage-diagonal tiles treat elements with col > row as zero (lower-triangular operand)
+  int ntiles;     // output tiles of this op (set by the launcher)
+  int alpha_neg;  // alpha = -1 instead of +1
+  int beta_one;   // beta = 1 instead of 0
+};
+
+struct GemmLaunch {
+  GemmOp op[2];
+  int nops;
+  const int* info;  // device flag: kernels return immediately when *info != 0
+};
+
+// ---- launchers (kernels.hip), T in {double, float} ------------------------------------------------------------
+template <typename T>
+void launch_gemm(const GemmLaunch& g, int tile, hipStream_t s);  // tile in {32, 64, 128}
+
+template <typename T>
+void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s);
+
+// Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag.
+template <typename T>
+void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s);
+
+// alpha = X^T (X y), lml pieces.  X lower-triangular np x np in W2.  part: [np/256][np] scratch.
+template <typename T>
+void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, T* wbuf, double* part, T* alpha,
+                      EvalOut* out, const int* info, hipStream_t s);
+
+// lml gradient: g_j = 1/2 sum_ik (alpha alpha^T - Kinv)_ik dK_ik/dtheta_j without materialising dK.
+template <typename T>
+void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
+                      double* part, EvalOut* out, const int* info, hipStream_t s);
+size_t gradtrace_part_elems(int np, int d);
+
+template <typename T>
+void launch_symmetrize(T* A, int np, hipStream_t s);  // mirror lower -> upper
+
+// predict: Kstar [mp x np] (rows = candidates), mean, var
+template <typename T>
+void launch_kstar(const T* Xs, int m, int mp, const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* Ks,
+                  hipStream_t s);
+template <typename T>
+void launch_pred_mean(const T* Ks, int m, int np, const T* alpha, T* mean, hipStream_t s);
+template <typename T>
+void launch_pred_var(const T* Ks, const T* Q, int m, int np, const EvalParams* P, T* var, EvalOut* out, hipStream_t s);
+
+void launch_set_info(int* info, int value, hipStream_t s);
+
+}  // namespace hbegp

@@ -1,0 +1,957 @@
+// hbegp.cpp — host runtime and C ABI of the MI355X GP engine (see include/hbegp.h).
+//
+// Layout in HBM (per evaluation slot, all row-major with leading dimension np = n rounded up to 128):
+//   W1   np x np   kernel matrix K (lower) -> trailing Schur complements / scratch during the factorisation
+//   W2   np x np   X = L^-1 (lower), built block by block while the Cholesky recursion runs
+//   Kinv np x np   x2 (ping-pong): K^-1 = X^T X (lower); the copy holding the best lml so far is never overwritten
+//   alpha np       x2 (ping-pong)
+// The padding rows/cols carry an identity block, so every kernel works on whole 128-tiles.
+//
+// One evaluation (lml.rs:29-79) = kmat -> chol_inv recursion (leaf + tile GEMMs) -> alpha/lml -> lauum -> gradtrace,
+// captured once per slot into a hipGraph and replayed for every theta the optimiser asks for.
+#include "../include/hbegp.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "engine.hpp"
+#include "lbfgsb.hpp"
+
+namespace hbegp {
+void init_kernels();  // kernels.hip: per-device function attributes (must run before any graph capture)
+}
+
+using namespace hbegp;
+
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error = "";
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+struct HipError {
+  hipError_t e;
+  const char* what;
+  int line;
+};
+#define HIPCHECK(x)                                \
+  do {                                             \
+    hipError_t _e = (x);                           \
+    if (_e != hipSuccess) throw HipError{_e, #x, __LINE__}; \
+  } while (0)
+
+static int hip_fail(const HipError& he) {
+  return fail(he.e == hipErrorOutOfMemory ? HBEGP_ENOMEM : HBEGP_EHIP, "HIP error %d (%s) in %s at hbegp.cpp:%d", (int)he.e,
+              hipGetErrorString(he.e), he.what, he.line);
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+struct hbegp_ctx {
+  std::vector<int> devs;
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// theta (log space) -> clamped linear-space parameters (fit.rs:94-96)
+static void theta_to_params(const double* theta, const double* lo, const double* hi, int d, EvalParams* P) {
+  auto clampv = [&](double v, int i) {
+    if (!lo || !hi) return v;
+    if (v < lo[i]) return lo[i];  // bounded_value.rs:43-56
+    if (hi[i] < v) return hi[i];
+    return v;
+  };
+  P->noise = std::exp(theta[0]);  // not clamped (fit.rs:96)
+  P->amp = clampv(std::exp(theta[1]), 1);
+  for (int k = 0; k < d; ++k) P->ell[k] = clampv(std::exp(theta[2 + k]), 2 + k);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// timing support for hbegp_problem_time_eval
+struct PhaseTimer {
+  enum Kind { KMAT = 0, GEMM = 1, LEAF = 2, LAUUM = 3, ALPHA = 4, GRAD = 5, NKIND = 6 };
+  struct Rec {
+    hipEvent_t a, b;
+    int kind, tile;
+    double gflop;
+  };
+  std::vector<Rec> recs;
+  hipStream_t s;
+  void begin(int kind, int tile = 0, double gflop = 0) {
+    Rec r;
+    HIPCHECK(hipEventCreate(&r.a));
+    HIPCHECK(hipEventCreate(&r.b));
+    r.kind = kind; r.tile = tile; r.gflop = gflop;
+    HIPCHECK(hipEventRecord(r.a, s));
+    recs.push_back(r);
+  }
+  void end() { HIPCHECK(hipEventRecord(recs.back().b, s)); }
+};
+
+static int pick_tile(int tiles128) {
+  static const int forced = env_int("HBEGP_TILE", 0);
+  if (forced == 32 || forced == 64 || forced == 128) return forced;
+  if (tiles128 >= env_int("HBEGP_T128_MIN", 192)) return 128;
+  if (tiles128 >= env_int("HBEGP_T64_MIN", 24)) return 64;
+  return 32;
+}
+
+// algorithmic flops of one op (in 128-tile units): 2*128^3 per (tile, k-tile) pair, half for pairs that only
+// touch a triangle (storage-diagonal tile of a triangular operand, or a diagonal tile of a symmetric result)
+static double op_gflop(const GemmOp& op) {
+  double pairs = 0;
+  for (int i = 0; i < op.mi; ++i)
+    for (int j = 0; j < (op.c_lower ? i + 1 : op.nj); ++j) {
+      const int ti = op.ci0 + i, tj = op.cj0 + j;
+      int ka = op.k0, kb = op.k1;
+      if (op.klim == 1) kb = std::min(kb, tj + 1);
+      if (op.klim == 2) ka = std::max(ka, tj);
+      if (op.klim == 3) kb = std::min(kb, ti + 1);
+      if (op.klim == 4) ka = std::max(ka, ti);
+      for (int k = ka; k < kb; ++k) {
+        double w = 1.0;
+        if ((op.maskA && k == ti) || (op.maskB && k == tj)) w = 0.5;
+        if (op.c_lower && ti == tj) w = std::min(w, 0.5);
+        pairs += w;
+      }
+    }
+  return pairs * 2.0 * 128.0 * 128.0 * 128.0 * 1e-9;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct Slot {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  T *W1 = nullptr, *W2 = nullptr, *Kinv[2] = {nullptr, nullptr}, *alpha[2] = {nullptr, nullptr};
+  T *ldiag = nullptr, *wbuf = nullptr;
+  double *part_t = nullptr, *part_g = nullptr;
+  EvalParams* dP = nullptr;
+  EvalOut* dOut = nullptr;
+  EvalParams* hP = nullptr;  // pinned
+  EvalOut* hOut = nullptr;   // pinned
+  hipGraphExec_t graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [target][want_grad]
+  // capture state (fit.rs:116-125)
+  int best_idx = -1;  // which ping-pong buffer holds the best evaluation so far
+  double best_lml = -std::numeric_limits<double>::infinity();
+  int best_run = 0, best_eval = 0;
+  std::vector<double> best_theta;
+  int last_target = 0;  // buffer written by the most recent evaluation
+};
+
+struct ProblemBase {
+  hbegp_ctx* ctx = nullptr;
+  int n = 0, d = 0, np = 0, nu2 = 5, n_slots = 1;
+  bool is_f32 = false;
+  virtual ~ProblemBase() {}
+  virtual int eval(int dev, int slot, const double* theta, const double* lo, const double* hi, double* lml, double* grad) = 0;
+  virtual int time_eval(int dev, int slot, const double* theta, int reps, double* phase_ms) = 0;
+};
+struct hbegp_problem {
+  std::unique_ptr<ProblemBase> impl;
+};
+
+template <typename T>
+struct Problem : ProblemBase {
+  std::vector<T*> Xd, yd;                 // per device
+  std::vector<std::vector<Slot<T>>> slots;  // [device][slot]
+
+  Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_) {
+    ctx = c; n = n_; d = d_; np = round_up(n_, NB); n_slots = n_slots_;
+    nu2 = (int)std::lround(2 * nu);
+    is_f32 = sizeof(T) == 4;
+    const size_t nn = (size_t)np * np;
+    Xd.assign(c->devs.size(), nullptr);
+    yd.assign(c->devs.size(), nullptr);
+    slots.resize(c->devs.size());
+    for (size_t di = 0; di < c->devs.size(); ++di) {
+      HIPCHECK(hipSetDevice(c->devs[di]));
+      HIPCHECK(hipMalloc(&Xd[di], sizeof(T) * (size_t)n * d));
+      HIPCHECK(hipMalloc(&yd[di], sizeof(T) * np));
+      HIPCHECK(hipMemset(yd[di], 0, sizeof(T) * np));
+      HIPCHECK(hipMemcpy(Xd[di], X, sizeof(T) * (size_t)n * d, hipMemcpyHostToDevice));
+      HIPCHECK(hipMemcpy(yd[di], y, sizeof(T) * n, hipMemcpyHostToDevice));
+      slots[di].resize(n_slots);
+      for (auto& s : slots[di]) {
+        s.dev = c->devs[di];
+        HIPCHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIPCHECK(hipMalloc(&s.W1, sizeof(T) * nn));
+        HIPCHECK(hipMalloc(&s.W2, sizeof(T) * nn));
+        for (int b = 0; b < 2; ++b) {
+          HIPCHECK(hipMalloc(&s.Kinv[b], sizeof(T) * nn));
+          HIPCHECK(hipMalloc(&s.alpha[b], sizeof(T) * np));
+        }
+        // W2's strict upper part is never written by the engine but full tiles of it are loaded (and masked) by
+        // the GEMM loader: keep it finite.
+        HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
+        HIPCHECK(hipMemset(s.W1, 0, sizeof(T) * nn));
+        HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
+        HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));
+        HIPCHECK(hipMalloc(&s.part_t, sizeof(double) * (size_t)((np + 255) / 256) * np));
+        HIPCHECK(hipMalloc(&s.part_g, sizeof(double) * gradtrace_part_elems(np, d)));
+        HIPCHECK(hipMalloc(&s.dP, sizeof(EvalParams)));
+        HIPCHECK(hipMalloc(&s.dOut, sizeof(EvalOut)));
+        HIPCHECK(hipMemset(s.dOut, 0, sizeof(EvalOut)));
+        HIPCHECK(hipHostMalloc(&s.hP, sizeof(EvalParams), hipHostMallocDefault));
+        HIPCHECK(hipHostMalloc(&s.hOut, sizeof(EvalOut), hipHostMallocDefault));
+        memset(s.hP, 0, sizeof(EvalParams));
+        memset(s.hOut, 0, sizeof(EvalOut));
+      }
+      HIPCHECK(hipDeviceSynchronize());
+    }
+  }
+  ~Problem() override {
+    for (size_t di = 0; di < slots.size(); ++di) {
+      (void)hipSetDevice(ctx->devs[di]);
+      for (auto& s : slots[di]) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b)
+            if (s.graph[a][b]) (void)hipGraphExecDestroy(s.graph[a][b]);
+        (void)hipFree(s.W1); (void)hipFree(s.W2);
+        for (int b = 0; b < 2; ++b) { (void)hipFree(s.Kinv[b]); (void)hipFree(s.alpha[b]); }
+        (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
+        (void)hipFree(s.dP); (void)hipFree(s.dOut);
+        (void)hipHostFree(s.hP); (void)hipHostFree(s.hOut);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+      }
+      (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
+    }
+  }
+
+  void gemm(Slot<T>& s, GemmLaunch& g, PhaseTimer* tm, int kind) {
+    g.info = &s.dOut->info;
+    int tiles = 0;
+    double gf = 0;
+    for (int i = 0; i < g.nops; ++i) {
+      const GemmOp& op = g.op[i];
+      tiles += op.c_lower ? op.mi * (op.mi + 1) / 2 : op.mi * op.nj;
+      if (tm) gf += op_gflop(op);
+    }
+    const int tile = pick_tile(tiles);
+    if (tm) tm->begin(kind, tile, gf);
+    launch_gemm<T>(g, tile, s.stream);
+    if (tm) tm->end();
+  }
+
+  // Cholesky + inverse of the factor on the diagonal block range [lo, hi) (units of 128): on return W2 holds
+  // X = L^-1 on that range (lower), ldiag the diagonal of L.
+  void chol_inv(Slot<T>& s, int lo, int hi, PhaseTimer* tm) {
+    if (hi - lo == 1) {
+      if (tm) tm->begin(PhaseTimer::LEAF);
+      launch_leaf<T>(s.W1, s.W2, np, lo, s.ldiag, &s.dOut->info, s.stream);
+      if (tm) tm->end();
+      return;
+    }
+    const int mid = lo + (hi - lo) / 2;
+    chol_inv(s, lo, mid, tm);
+    GemmOp base{};
+    base.lda = base.ldb = base.ldc = np;
+    {
+      // T = A21 * X11^T  -> W2[2,1]      (TRSM of potrf as a product with the explicit inverse)
+      GemmLaunch g{};
+      g.nops = 1;
+      GemmOp& op = g.op[0];
+      op = base;
+      op.A = s.W1; op.B = s.W2; op.C = s.W2;
+      op.a_kmajor = 0; op.b_kmajor = 0;
+      op.ci0 = mid; op.mi = hi - mid; op.cj0 = lo; op.nj = mid - lo;
+      op.k0 = lo; op.k1 = mid; op.klim = 1; op.maskB = 1;
+      gemm(s, g, tm, PhaseTimer::GEMM);
+    }
+    {
+      // A22 -= T T^T (lower)   and   U = T * X11 -> W1[2,1]   (independent: one launch)
+      GemmLaunch g{};
+      g.nops = 2;
+      GemmOp& syrk = g.op[0];
+      syrk = base;
+      syrk.A = s.W2; syrk.B = s.W2; syrk.C = s.W1;
+      syrk.ci0 = mid; syrk.cj0 = mid; syrk.mi = hi - mid; syrk.nj = hi - mid; syrk.c_lower = 1;
+      syrk.k0 = lo; syrk.k1 = mid; syrk.alpha_neg = 1; syrk.beta_one = 1;
+      GemmOp& u = g.op[1];
+      u = base;
+      u.A = s.W2; u.B = s.W2; u.C = s.W1;
+      u.a_kmajor = 0; u.b_kmajor = 1;
+      u.ci0 = mid; u.mi = hi - mid; u.cj0 = lo; u.nj = mid - lo;
+      u.k0 = lo; u.k1 = mid; u.klim = 2; u.maskB = 1;
+      gemm(s, g, tm, PhaseTimer::GEMM);
+    }
+    chol_inv(s, mid, hi, tm);
+    {
+      // X21 = -X22 * U -> W2[2,1]
+      GemmLaunch g{};
+      g.nops = 1;
+      GemmOp& op = g.op[0];
+      op = base;
+      op.A = s.W2; op.B = s.W1; op.C = s.W2;
+      op.a_kmajor = 0; op.b_kmajor = 1;
+      op.ci0 = mid; op.mi = hi - mid; op.cj0 = lo; op.nj = mid - lo;
+      op.k0 = mid; op.k1 = hi; op.klim = 3; op.maskA = 1; op.alpha_neg = 1;
+      gemm(s, g, tm, PhaseTimer::GEMM);
+    }
+  }
+
+  void enqueue_eval(Slot<T>& s, size_t di, int target, bool want_grad, PhaseTimer* tm) {
+    const int nb = np / NB;
+    HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
+    HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+    const int* info = &s.dOut->info;
+    if (tm) tm->begin(PhaseTimer::KMAT);
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+    if (tm) tm->end();
+    chol_inv(s, 0, nb, tm);
+    if (tm) tm->begin(PhaseTimer::ALPHA);
+    launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);
+    if (tm) tm->end();
+    {
+      // K^-1 = X^T X (lower)  [LAUUM]
+      GemmLaunch g{};
+      g.nops = 1;
+      GemmOp& op = g.op[0];
+      op.lda = op.ldb = op.ldc = np;
+      op.A = s.W2; op.B = s.W2; op.C = s.Kinv[target];
+      op.a_kmajor = 1; op.b_kmajor = 1;
+      op.ci0 = 0; op.cj0 = 0; op.mi = nb; op.nj = nb; op.c_lower = 1;
+      op.k0 = 0; op.k1 = nb; op.klim = 4; op.maskA = 1; op.maskB = 1;
+      gemm(s, g, tm, PhaseTimer::LAUUM);
+    }
+    if (want_grad) {
+      if (tm) tm->begin(PhaseTimer::GRAD);
+      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream);
+      if (tm) tm->end();
+    }
+    HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+  }
+
+  // Run one evaluation on (device index di, slot si) into ping-pong buffer `target`; blocks until the result is on the host.
+  int run_eval(size_t di, int si, int target, bool want_grad, bool use_graph, double* lml, double* grad) {
+    Slot<T>& s = slots[di][si];
+    HIPCHECK(hipSetDevice(s.dev));
+    static const bool graphs_on = env_int("HBEGP_NO_GRAPH", 0) == 0;
+    if (use_graph && graphs_on) {
+      hipGraphExec_t& ge = s.graph[target][want_grad ? 1 : 0];
+      if (!ge) {
+        hipGraph_t gr = nullptr;
+        HIPCHECK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
+        try {
+          enqueue_eval(s, di, target, want_grad, nullptr);
+        } catch (...) {
+          (void)hipStreamEndCapture(s.stream, &gr);
+          throw;
+        }
+        HIPCHECK(hipStreamEndCapture(s.stream, &gr));
+        HIPCHECK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        HIPCHECK(hipGraphDestroy(gr));
+      }
+      HIPCHECK(hipGraphLaunch(ge, s.stream));
+    } else {
+      enqueue_eval(s, di, target, want_grad, nullptr);
+    }
+    HIPCHECK(hipStreamSynchronize(s.stream));
+    s.last_target = target;
+    const int p = d + 2;
+    if (s.hOut->info != 0) {
+      *lml = -std::numeric_limits<double>::infinity();
+      if (grad) for (int j = 0; j < p; ++j) grad[j] = 0.0;  // fit.rs:105-112
+      return HBEGP_NOT_PD;
+    }
+    *lml = s.hOut->lml;
+    if (grad) for (int j = 0; j < p; ++j) grad[j] = s.hOut->grad[j];
+    return HBEGP_OK;
+  }
+
+  int eval(int dev, int slot, const double* theta, const double* lo, const double* hi, double* lml, double* grad) override {
+    if (dev < 0 || dev >= (int)slots.size() || slot < 0 || slot >= n_slots) return fail(HBEGP_EINVAL, "bad device/slot index");
+    Slot<T>& s = slots[dev][slot];
+    theta_to_params(theta, lo, hi, d, s.hP);
+    // never overwrite the captured best: write into the other buffer
+    const int target = (s.best_idx < 0) ? 0 : 1 - s.best_idx;
+    return run_eval((size_t)dev, slot, target, grad != nullptr, true, lml, grad);
+  }
+
+  int time_eval(int dev, int slot, const double* theta, int reps, double* phase_ms) override {
+    if (dev < 0 || dev >= (int)slots.size() || slot < 0 || slot >= n_slots) return fail(HBEGP_EINVAL, "bad device/slot index");
+    Slot<T>& s = slots[dev][slot];
+    HIPCHECK(hipSetDevice(s.dev));
+    theta_to_params(theta, nullptr, nullptr, d, s.hP);
+    double lml;
+    std::vector<double> grad(d + 2);
+    int st = run_eval((size_t)dev, slot, 0, true, true, &lml, grad.data());  // warm-up + graph instantiation
+    if (st != HBEGP_OK) return st;
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, s.stream));
+    for (int r = 0; r < reps; ++r) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
+    HIPCHECK(hipEventRecord(e1, s.stream));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (phase_ms) {
+      for (int i = 0; i < 16; ++i) phase_ms[i] = 0;
+      phase_ms[6] = ms / reps;
+      // eager pass with one event pair per launch
+      const int treps = std::max(1, std::min(reps, 3));
+      for (int r = 0; r < treps; ++r) {
+        PhaseTimer tm;
+        tm.s = s.stream;
+        hipEvent_t t0, t1;
+        HIPCHECK(hipEventCreate(&t0));
+        HIPCHECK(hipEventCreate(&t1));
+        HIPCHECK(hipEventRecord(t0, s.stream));
+        enqueue_eval(s, (size_t)dev, 0, true, &tm);
+        HIPCHECK(hipEventRecord(t1, s.stream));
+        HIPCHECK(hipStreamSynchronize(s.stream));
+        float tot = 0;
+        HIPCHECK(hipEventElapsedTime(&tot, t0, t1));
+        phase_ms[14] += tot / treps;
+        for (auto& rec : tm.recs) {
+          float dt = 0;
+          HIPCHECK(hipEventElapsedTime(&dt, rec.a, rec.b));
+          const double v = dt / treps;
+          if (rec.kind == PhaseTimer::KMAT) phase_ms[0] += v;
+          if (rec.kind == PhaseTimer::GEMM) { phase_ms[1] += v; phase_ms[7] += 1.0 / treps; }
+          if (rec.kind == PhaseTimer::LEAF) { phase_ms[2] += v; phase_ms[15] += 1.0 / treps; }
+          if (rec.kind == PhaseTimer::LAUUM) phase_ms[3] += v;
+          if (rec.kind == PhaseTimer::ALPHA) phase_ms[4] += v;
+          if (rec.kind == PhaseTimer::GRAD) phase_ms[5] += v;
+          if (rec.kind == PhaseTimer::GEMM || rec.kind == PhaseTimer::LAUUM) {
+            const int o = rec.tile == 128 ? 8 : (rec.tile == 64 ? 10 : 12);
+            phase_ms[o] += v;
+            phase_ms[o + 1] += rec.gflop / treps;
+          }
+          (void)hipEventDestroy(rec.a);
+          (void)hipEventDestroy(rec.b);
+        }
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+      }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return HBEGP_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// model
+struct hbegp_model {
+  std::atomic<int> refs{1};
+  int dev = 0, n = 0, d = 0, np = 0, nu2 = 5;
+  bool is_f32 = false;
+  double lml = 0;
+  std::vector<double> theta;  // clamped, log space
+  void *X = nullptr, *alpha = nullptr, *Kinv = nullptr;  // device
+  EvalParams* dP = nullptr;
+  EvalOut* dOut = nullptr;
+  hipStream_t stream = nullptr;
+  // predict scratch (grow-only)
+  int cap_m = 0;
+  void *Xs = nullptr, *Ks = nullptr, *Q = nullptr, *mean = nullptr, *var = nullptr;
+  std::mutex mu;
+  ~hbegp_model() {
+    (void)hipSetDevice(dev);
+    if (stream) (void)hipStreamSynchronize(stream);
+    (void)hipFree(X); (void)hipFree(alpha); (void)hipFree(Kinv); (void)hipFree(dP); (void)hipFree(dOut);
+    (void)hipFree(Xs); (void)hipFree(Ks); (void)hipFree(Q); (void)hipFree(mean); (void)hipFree(var);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+template <typename T>
+static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double* theta_clamped, double lml) {
+  Slot<T>& s = prob.slots[di][si];
+  HIPCHECK(hipSetDevice(s.dev));
+  std::unique_ptr<hbegp_model> m(new hbegp_model());
+  m->dev = s.dev; m->n = prob.n; m->d = prob.d; m->np = prob.np; m->nu2 = prob.nu2; m->is_f32 = prob.is_f32; m->lml = lml;
+  m->theta.assign(theta_clamped, theta_clamped + prob.d + 2);
+  const size_t nn = (size_t)prob.np * prob.np;
+  HIPCHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  HIPCHECK(hipMalloc(&m->X, sizeof(T) * (size_t)prob.n * prob.d));
+  HIPCHECK(hipMalloc(&m->alpha, sizeof(T) * prob.np));
+  HIPCHECK(hipMalloc(&m->Kinv, sizeof(T) * nn));
+  HIPCHECK(hipMalloc(&m->dP, sizeof(EvalParams)));
+  HIPCHECK(hipMalloc(&m->dOut, sizeof(EvalOut)));
+  const int b = s.best_idx < 0 ? s.last_target : s.best_idx;
+  HIPCHECK(hipMemcpyAsync(m->X, prob.Xd[di], sizeof(T) * (size_t)prob.n * prob.d, hipMemcpyDeviceToDevice, m->stream));
+  HIPCHECK(hipMemcpyAsync(m->alpha, s.alpha[b], sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
+  HIPCHECK(hipMemcpyAsync(m->Kinv, s.Kinv[b], sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
+  launch_symmetrize<T>(static_cast<T*>(m->Kinv), prob.np, m->stream);  // invc_into() returns the full matrix (fit.rs:60,168)
+  EvalParams P;
+  memset(&P, 0, sizeof(P));
+  theta_to_params(theta_clamped, nullptr, nullptr, prob.d, &P);
+  HIPCHECK(hipMemcpyAsync(m->dP, &P, sizeof(P), hipMemcpyHostToDevice, m->stream));
+  HIPCHECK(hipStreamSynchronize(m->stream));
+  return m.release();
+}
+
+template <typename T>
+static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, int* n_warn) {
+  std::lock_guard<std::mutex> lock(m->mu);
+  HIPCHECK(hipSetDevice(m->dev));
+  const int mp = round_up(std::max(cnt, 1), NB);
+  if (mp > m->cap_m) {
+    (void)hipFree(m->Xs); (void)hipFree(m->Ks); (void)hipFree(m->Q); (void)hipFree(m->mean); (void)hipFree(m->var);
+    m->Xs = m->Ks = m->Q = m->mean = m->var = nullptr;
+    m->cap_m = 0;
+    HIPCHECK(hipMalloc(&m->Xs, sizeof(T) * (size_t)mp * m->d));
+    HIPCHECK(hipMalloc(&m->Ks, sizeof(T) * (size_t)mp * m->np));
+    HIPCHECK(hipMalloc(&m->Q, sizeof(T) * (size_t)mp * m->np));
+    HIPCHECK(hipMalloc(&m->mean, sizeof(T) * mp));
+    HIPCHECK(hipMalloc(&m->var, sizeof(T) * mp));
+    m->cap_m = mp;
+  }
+  hipStream_t s = m->stream;
+  HIPCHECK(hipMemcpyAsync(m->Xs, Xs, sizeof(T) * (size_t)cnt * m->d, hipMemcpyHostToDevice, s));
+  HIPCHECK(hipMemsetAsync(m->dOut, 0, sizeof(EvalOut), s));
+  launch_kstar<T>(static_cast<T*>(m->Xs), cnt, mp, static_cast<T*>(m->X), m->n, m->d, m->np, m->nu2, m->dP,
+                  static_cast<T*>(m->Ks), s);
+  launch_pred_mean<T>(static_cast<T*>(m->Ks), cnt, m->np, static_cast<T*>(m->alpha), static_cast<T*>(m->mean), s);
+  if (var) {
+    // Q = Kstar * Kinv (Kinv symmetric: rows of Kinv are read along the contraction index)
+    GemmLaunch g{};
+    g.nops = 1;
+    g.info = &m->dOut->info;
+    GemmOp& op = g.op[0];
+    op.A = m->Ks; op.B = m->Kinv; op.C = m->Q;
+    op.lda = m->np; op.ldb = m->np; op.ldc = m->np;
+    op.ci0 = 0; op.cj0 = 0; op.mi = mp / NB; op.nj = m->np / NB;
+    op.k0 = 0; op.k1 = m->np / NB;
+    launch_gemm<T>(g, pick_tile(op.mi * op.nj), s);
+    launch_pred_var<T>(static_cast<T*>(m->Ks), static_cast<T*>(m->Q), cnt, m->np, m->dP, static_cast<T*>(m->var), m->dOut, s);
+  }
+  HIPCHECK(hipMemcpyAsync(mean, m->mean, sizeof(T) * cnt, hipMemcpyDeviceToHost, s));
+  if (var) HIPCHECK(hipMemcpyAsync(var, m->var, sizeof(T) * cnt, hipMemcpyDeviceToHost, s));
+  EvalOut out;
+  HIPCHECK(hipMemcpyAsync(&out, m->dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  if (n_warn) *n_warn = var ? out.n_warn : 0;
+  return HBEGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fit (fit.rs:71-176 + gradmin.rs:7-60)
+template <typename T>
+static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double nu, const double* theta0, const double* lo,
+                  const double* hi, const double* starts, int n_restarts, const hbegp_fit_options* opt_in,
+                  double* theta_best, double* lml_best, hbegp_model** model_out) {
+  hbegp_fit_options opt{};
+  if (opt_in) opt = *opt_in;
+  if (opt.maxeval <= 0) opt.maxeval = 150;
+  const int p = d + 2;
+  const int nruns = 1 + std::max(0, n_restarts);
+  const int ndev = (int)ctx->devs.size();
+  const int max_conc = std::max(1, env_int("HBEGP_MAX_CONCURRENT", 4));
+  // workers: device di gets min(runs on that device, max_conc) slots; run r -> device r % ndev
+  std::vector<int> runs_on(ndev, 0);
+  for (int r = 0; r < nruns; ++r) runs_on[r % ndev]++;
+  int n_slots = 1;
+  for (int di = 0; di < ndev; ++di) n_slots = std::max(n_slots, std::min(runs_on[di], max_conc));
+  Problem<T> prob(ctx, X, y, n, d, nu, n_slots);
+
+  std::vector<double> lnlo(p), lnhi(p);
+  for (int i = 0; i < p; ++i) {
+    lnlo[i] = std::log(lo[i]);
+    lnhi[i] = std::log(hi[i]);
+  }
+  std::mutex trace_mu;
+  int trace_n = 0;
+  std::string err;
+  std::mutex err_mu;
+
+  auto worker = [&](int di, int si) {
+    try {
+      HIPCHECK(hipSetDevice(ctx->devs[di]));
+      Slot<T>& s = prob.slots[di][si];
+      const int nslots_here = std::min(runs_on[di], max_conc);
+      // runs assigned to this device: r = di, di+ndev, ...; this worker takes every nslots_here-th of them
+      int local = 0;
+      for (int r = di; r < nruns; r += ndev, ++local) {
+        if (local % nslots_here != si) continue;
+        std::vector<double> x(p);
+        if (r == 0) for (int i = 0; i < p; ++i) x[i] = theta0[i];
+        else for (int i = 0; i < p; ++i) x[i] = starts[(size_t)(r - 1) * p + i];
+        int eval_idx = 0;
+        Objective obj = [&](const double* th, double* grad) -> double {
+          theta_to_params(th, lo, hi, d, s.hP);
+          const int target = (s.best_idx < 0) ? 0 : 1 - s.best_idx;
+          double lml;
+          const int st = prob.run_eval((size_t)di, si, target, true, true, &lml, grad);
+          const int my_eval = eval_idx++;
+          if (opt.trace_cap > 0) {
+            std::lock_guard<std::mutex> lk(trace_mu);
+            if (trace_n < opt.trace_cap) {
+              const int tI = trace_n++;
+              if (opt.trace_theta) memcpy(opt.trace_theta + (size_t)tI * p, th, sizeof(double) * p);
+              if (opt.trace_lml) opt.trace_lml[tI] = lml;
+              if (opt.trace_grad) memcpy(opt.trace_grad + (size_t)tI * p, grad, sizeof(double) * p);
+              if (opt.trace_run) opt.trace_run[tI] = r;
+            }
+          }
+          if (st != HBEGP_OK) return std::numeric_limits<double>::infinity();  // fit.rs:105-112
+          // capture (fit.rs:116-125): strictly greater lml wins; ties keep the earlier (run, eval)
+          if (s.best_idx < 0 || lml > s.best_lml) {
+            s.best_idx = target;
+            s.best_lml = lml;
+            s.best_run = r;
+            s.best_eval = my_eval;
+            s.best_theta.assign(th, th + p);
+          }
+          for (int j = 0; j < p; ++j) grad[j] = -grad[j];  // fit.rs:128-133
+          return -lml;
+        };
+        LbfgsOptions lo_opt;
+        lo_opt.maxeval = opt.maxeval;
+        lo_opt.fixed_work = opt.fixed_work != 0;
+        if (opt.lbfgs_memory > 0) lo_opt.memory = opt.lbfgs_memory;
+        lbfgsb_minimize(obj, x.data(), lnlo.data(), lnhi.data(), p, lo_opt);
+      }
+    } catch (const HipError& he) {
+      hip_fail(he);
+      std::lock_guard<std::mutex> lk(err_mu);
+      err = g_last_error;
+    }
+  };
+
+  std::vector<std::thread> threads;
+  for (int di = 0; di < ndev; ++di)
+    for (int si = 0; si < std::min(runs_on[di], max_conc); ++si) threads.emplace_back(worker, di, si);
+  for (auto& t : threads) t.join();
+  if (opt.trace_count) *opt.trace_count = trace_n;
+  if (!err.empty()) return fail(HBEGP_EHIP, "%s", err.c_str());
+
+  // global arg-max over the per-slot captures, ties -> lowest (run, eval)
+  int bdi = -1, bsi = -1;
+  for (int di = 0; di < ndev; ++di)
+    for (int si = 0; si < (int)prob.slots[di].size(); ++si) {
+      const Slot<T>& s = prob.slots[di][si];
+      if (s.best_idx < 0) continue;
+      bool better = bdi < 0;
+      if (!better) {
+        const Slot<T>& b = prob.slots[bdi][bsi];
+        better = s.best_lml > b.best_lml ||
+                 (s.best_lml == b.best_lml && (s.best_run < b.best_run || (s.best_run == b.best_run && s.best_eval < b.best_eval)));
+      }
+      if (better) { bdi = di; bsi = si; }
+    }
+  if (bdi < 0) return fail(HBEGP_ALL_FAILED, "every evaluation of the fit failed (kernel matrix not positive definite)");
+  Slot<T>& best = prob.slots[bdi][bsi];
+  // clamp the captured parameters (fit.rs:155-164)
+  std::vector<double> th(p);
+  for (int i = 0; i < p; ++i) {
+    double v = std::exp(best.best_theta[i]);
+    if (v < lo[i]) v = lo[i];
+    if (hi[i] < v) v = hi[i];
+    th[i] = std::log(v);
+  }
+  if (theta_best) memcpy(theta_best, th.data(), sizeof(double) * p);
+  if (lml_best) *lml_best = best.best_lml;
+  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml);
+  return HBEGP_OK;
+}
+
+template <typename T>
+static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double nu, const double* theta, const double* lo,
+                     const double* hi, hbegp_model** model_out) {
+  hbegp_ctx one;
+  one.devs = {ctx->devs[0]};
+  Problem<T> prob(&one, X, y, n, d, nu, 1);
+  const int p = d + 2;
+  Slot<T>& s = prob.slots[0][0];
+  theta_to_params(theta, lo, hi, d, s.hP);
+  double lml;
+  const int st = prob.run_eval(0, 0, 0, false, false, &lml, nullptr);
+  if (st != HBEGP_OK) return fail(HBEGP_NOT_PD, "Kernel matrix must be invertible.");  // fit.rs:55
+  s.best_idx = 0;
+  std::vector<double> th(theta, theta + p);
+  if (lo && hi)
+    for (int i = 0; i < p; ++i) {
+      double v = std::exp(theta[i]);
+      if (v < lo[i]) v = lo[i];
+      if (hi[i] < v) v = hi[i];
+      th[i] = std::log(v);
+    }
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml);
+  return HBEGP_OK;
+}
+
+static int check_args(hbegp_ctx* ctx, const void* X, const void* y, int n, int d, double nu) {
+  if (!ctx) return fail(HBEGP_EINVAL, "ctx is NULL");
+  if (!X || !y) return fail(HBEGP_EINVAL, "X/y is NULL");
+  if (n < 1) return fail(HBEGP_EINVAL, "n must be >= 1 (got %d)", n);
+  if (d < 1 || d > MAXD) return fail(HBEGP_EINVAL, "d must be in 1..%d (got %d)", MAXD, d);
+  if (!(nu == 0.5 || nu == 1.5 || nu == 2.5))
+    return fail(HBEGP_EINVAL, "Matern kernel with arbitrary values for nu is unimplemented (got %g)", nu);  // matern_kernel.rs:79
+  return HBEGP_OK;
+}
+
+#define GUARD_BEGIN try {
+#define GUARD_END                                   \
+  }                                                 \
+  catch (const HipError& he) { return hip_fail(he); } \
+  catch (const std::bad_alloc&) { return fail(HBEGP_ENOMEM, "host allocation failed"); }
+
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int hbegp_version(void) { return HBEGP_VERSION; }
+
+int hbegp_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < cnt; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+const char* hbegp_last_error(void) { return g_last_error.c_str(); }
+
+int hbegp_ctx_create(int n_devices, const int* device_ids, hbegp_ctx** out) {
+  if (!out || n_devices < 1) return fail(HBEGP_EINVAL, "n_devices must be >= 1");
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt < 1)
+    return fail(HBEGP_ENODEV, "no HIP device available: libhbegp has no CPU fallback");
+  GUARD_BEGIN
+  std::unique_ptr<hbegp_ctx> ctx(new hbegp_ctx());
+  for (int i = 0; i < n_devices; ++i) {
+    const int id = device_ids ? device_ids[i] : i;
+    if (id < 0 || id >= cnt) return fail(HBEGP_ENODEV, "device %d not present (%d visible)", id, cnt);
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(HBEGP_ENODEV, "device %d is %s; this library only carries gfx950 code", id, prop.gcnArchName);
+    HIPCHECK(hipSetDevice(id));
+    init_kernels();
+    ctx->devs.push_back(id);
+  }
+  *out = ctx.release();
+  return HBEGP_OK;
+  GUARD_END
+}
+void hbegp_ctx_destroy(hbegp_ctx* ctx) { delete ctx; }
+
+int hbegp_problem_create_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, int n_slots,
+                             hbegp_problem** out) {
+  if (int e = check_args(ctx, X, y, n, d, nu)) return e;
+  if (!out || n_slots < 1) return fail(HBEGP_EINVAL, "bad out/n_slots");
+  GUARD_BEGIN
+  std::unique_ptr<hbegp_problem> p(new hbegp_problem());
+  p->impl.reset(new Problem<double>(ctx, X, y, n, d, nu, n_slots));
+  *out = p.release();
+  return HBEGP_OK;
+  GUARD_END
+}
+int hbegp_problem_create_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, int n_slots,
+                             hbegp_problem** out) {
+  if (int e = check_args(ctx, X, y, n, d, nu)) return e;
+  if (!out || n_slots < 1) return fail(HBEGP_EINVAL, "bad out/n_slots");
+  GUARD_BEGIN
+  std::unique_ptr<hbegp_problem> p(new hbegp_problem());
+  p->impl.reset(new Problem<float>(ctx, X, y, n, d, nu, n_slots));
+  *out = p.release();
+  return HBEGP_OK;
+  GUARD_END
+}
+void hbegp_problem_destroy(hbegp_problem* prob) { delete prob; }
+
+int hbegp_problem_eval(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo, const double* hi,
+                       double* lml, double* grad) {
+  if (!prob || !theta || !lml) return fail(HBEGP_EINVAL, "NULL argument");
+  GUARD_BEGIN
+  return prob->impl->eval(dev, slot, theta, lo, hi, lml, grad);
+  GUARD_END
+}
+
+int hbegp_problem_time_eval(hbegp_problem* prob, int dev, int slot, const double* theta, int reps, double* phase_ms) {
+  if (!prob || !theta || reps < 1) return fail(HBEGP_EINVAL, "bad argument");
+  GUARD_BEGIN
+  return prob->impl->time_eval(dev, slot, theta, reps, phase_ms);
+  GUARD_END
+}
+
+}  // extern "C"
+template <typename T>
+static int problem_get(hbegp_problem* prob, int dev, int slot, T* alpha, T* kinv, T* ldiag) {
+  if (!prob) return fail(HBEGP_EINVAL, "NULL problem");
+  auto* p = dynamic_cast<Problem<T>*>(prob->impl.get());
+  if (!p) return fail(HBEGP_EINVAL, "element type mismatch");
+  if (dev < 0 || dev >= (int)p->slots.size() || slot < 0 || slot >= p->n_slots) return fail(HBEGP_EINVAL, "bad device/slot index");
+  GUARD_BEGIN
+  Slot<T>& s = p->slots[dev][slot];
+  HIPCHECK(hipSetDevice(s.dev));
+  const int b = s.last_target, n = p->n, np = p->np;
+  if (alpha) HIPCHECK(hipMemcpy(alpha, s.alpha[b], sizeof(T) * n, hipMemcpyDeviceToHost));
+  if (ldiag) HIPCHECK(hipMemcpy(ldiag, s.ldiag, sizeof(T) * n, hipMemcpyDeviceToHost));
+  if (kinv) {
+    std::vector<T> tmp((size_t)np * np);
+    HIPCHECK(hipMemcpy(tmp.data(), s.Kinv[b], sizeof(T) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j <= i; ++j) kinv[(size_t)i * n + j] = kinv[(size_t)j * n + i] = tmp[(size_t)i * np + j];
+  }
+  return HBEGP_OK;
+  GUARD_END
+}
+extern "C" {
+int hbegp_problem_get_f64(hbegp_problem* prob, int dev, int slot, double* alpha, double* kinv, double* ldiag) {
+  return problem_get<double>(prob, dev, slot, alpha, kinv, ldiag);
+}
+int hbegp_problem_get_f32(hbegp_problem* prob, int dev, int slot, float* alpha, float* kinv, float* ldiag) {
+  return problem_get<float>(prob, dev, slot, alpha, kinv, ldiag);
+}
+
+}  // extern "C"
+template <typename T>
+static int problem_kmat(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo, const double* hi, T* K) {
+  if (!prob || !theta || !K) return fail(HBEGP_EINVAL, "NULL argument");
+  auto* p = dynamic_cast<Problem<T>*>(prob->impl.get());
+  if (!p) return fail(HBEGP_EINVAL, "element type mismatch");
+  if (dev < 0 || dev >= (int)p->slots.size() || slot < 0 || slot >= p->n_slots) return fail(HBEGP_EINVAL, "bad device/slot index");
+  GUARD_BEGIN
+  Slot<T>& s = p->slots[dev][slot];
+  HIPCHECK(hipSetDevice(s.dev));
+  theta_to_params(theta, lo, hi, p->d, s.hP);
+  HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
+  HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+  launch_kmat<T>(p->Xd[dev], p->n, p->d, p->np, p->nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+  const int n = p->n, np = p->np;
+  std::vector<T> tmp((size_t)np * np);
+  HIPCHECK(hipMemcpyAsync(tmp.data(), s.W1, sizeof(T) * tmp.size(), hipMemcpyDeviceToHost, s.stream));
+  HIPCHECK(hipStreamSynchronize(s.stream));
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) K[(size_t)i * n + j] = K[(size_t)j * n + i] = tmp[(size_t)i * np + j];
+  return HBEGP_OK;
+  GUARD_END
+}
+extern "C" {
+int hbegp_problem_kmat_f64(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo, const double* hi,
+                           double* K) {
+  return problem_kmat<double>(prob, dev, slot, theta, lo, hi, K);
+}
+int hbegp_problem_kmat_f32(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo, const double* hi,
+                           float* K) {
+  return problem_kmat<float>(prob, dev, slot, theta, lo, hi, K);
+}
+
+int hbegp_fit_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, const double* theta0,
+                  const double* lo, const double* hi, const double* starts, int n_restarts, const hbegp_fit_options* opt,
+                  double* theta_best, double* lml_best, hbegp_model** model) {
+  if (int e = check_args(ctx, X, y, n, d, nu)) return e;
+  if (!theta0 || !lo || !hi || (n_restarts > 0 && !starts)) return fail(HBEGP_EINVAL, "theta0/lo/hi/starts is NULL");
+  GUARD_BEGIN
+  return do_fit<double>(ctx, X, y, n, d, nu, theta0, lo, hi, starts, n_restarts, opt, theta_best, lml_best, model);
+  GUARD_END
+}
+int hbegp_fit_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta0,
+                  const double* lo, const double* hi, const double* starts, int n_restarts, const hbegp_fit_options* opt,
+                  double* theta_best, double* lml_best, hbegp_model** model) {
+  if (int e = check_args(ctx, X, y, n, d, nu)) return e;
+  if (!theta0 || !lo || !hi || (n_restarts > 0 && !starts)) return fail(HBEGP_EINVAL, "theta0/lo/hi/starts is NULL");
+  GUARD_BEGIN
+  return do_fit<float>(ctx, X, y, n, d, nu, theta0, lo, hi, starts, n_restarts, opt, theta_best, lml_best, model);
+  GUARD_END
+}
+
+int hbegp_extend_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, const double* theta,
+                     const double* lo, const double* hi, hbegp_model** model) {
+  if (int e = check_args(ctx, X, y, n, d, nu)) return e;
+  if (!theta) return fail(HBEGP_EINVAL, "theta is NULL");
+  GUARD_BEGIN
+  return do_extend<double>(ctx, X, y, n, d, nu, theta, lo, hi, model);
+  GUARD_END
+}
+int hbegp_extend_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta,
+                     const double* lo, const double* hi, hbegp_model** model) {
+  if (int e = check_args(ctx, X, y, n, d, nu)) return e;
+  if (!theta) return fail(HBEGP_EINVAL, "theta is NULL");
+  GUARD_BEGIN
+  return do_extend<float>(ctx, X, y, n, d, nu, theta, lo, hi, model);
+  GUARD_END
+}
+
+int hbegp_predict_f64(hbegp_model* model, const double* Xs, int m, double* mean, double* var, int* n_warn) {
+  if (!model || !Xs || !mean || m < 0) return fail(HBEGP_EINVAL, "bad argument");
+  if (model->is_f32) return fail(HBEGP_EINVAL, "model holds f32 data");
+  if (m == 0) { if (n_warn) *n_warn = 0; return HBEGP_OK; }
+  GUARD_BEGIN
+  return model_predict<double>(model, Xs, m, mean, var, n_warn);
+  GUARD_END
+}
+int hbegp_predict_f32(hbegp_model* model, const float* Xs, int m, float* mean, float* var, int* n_warn) {
+  if (!model || !Xs || !mean || m < 0) return fail(HBEGP_EINVAL, "bad argument");
+  if (!model->is_f32) return fail(HBEGP_EINVAL, "model holds f64 data");
+  if (m == 0) { if (n_warn) *n_warn = 0; return HBEGP_OK; }
+  GUARD_BEGIN
+  return model_predict<float>(model, Xs, m, mean, var, n_warn);
+  GUARD_END
+}
+
+int hbegp_model_info(const hbegp_model* model, int* n, int* d, int* is_f32, double* nu, double* lml) {
+  if (!model) return fail(HBEGP_EINVAL, "NULL model");
+  if (n) *n = model->n;
+  if (d) *d = model->d;
+  if (is_f32) *is_f32 = model->is_f32 ? 1 : 0;
+  if (nu) *nu = model->nu2 / 2.0;
+  if (lml) *lml = model->lml;
+  return HBEGP_OK;
+}
+
+}  // extern "C"
+template <typename T>
+static int model_get(hbegp_model* m, double* theta, T* alpha, T* kinv) {
+  if (!m) return fail(HBEGP_EINVAL, "NULL model");
+  if (m->is_f32 != (sizeof(T) == 4)) return fail(HBEGP_EINVAL, "element type mismatch");
+  GUARD_BEGIN
+  std::lock_guard<std::mutex> lock(m->mu);
+  HIPCHECK(hipSetDevice(m->dev));
+  if (theta) memcpy(theta, m->theta.data(), sizeof(double) * m->theta.size());
+  if (alpha) HIPCHECK(hipMemcpy(alpha, m->alpha, sizeof(T) * m->n, hipMemcpyDeviceToHost));
+  if (kinv) HIPCHECK(hipMemcpy2D(kinv, sizeof(T) * m->n, m->Kinv, sizeof(T) * m->np, sizeof(T) * m->n, m->n, hipMemcpyDeviceToHost));
+  return HBEGP_OK;
+  GUARD_END
+}
+extern "C" {
+int hbegp_model_get_f64(hbegp_model* model, double* theta, double* alpha, double* kinv) {
+  return model_get<double>(model, theta, alpha, kinv);
+}
+int hbegp_model_get_f32(hbegp_model* model, double* theta, float* alpha, float* kinv) {
+  return model_get<float>(model, theta, alpha, kinv);
+}
+void hbegp_model_retain(hbegp_model* model) {
+  if (model) model->refs.fetch_add(1);
+}
+void hbegp_model_release(hbegp_model* model) {
+  if (model && model->refs.fetch_sub(1) == 1) delete model;
+}
+
+double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, const double* lo, const double* hi, int n,
+                                  int maxeval) {
+  LbfgsOptions opt;
+  opt.maxeval = maxeval > 0 ? maxeval : 150;
+  Objective obj = [&](const double* xx, double* g) { return f(xx, g, user); };
+  return lbfgsb_minimize(obj, x, lo, hi, n, opt).f;
+}
+
+}  // extern "C"

@@ -1,0 +1,965 @@
+// kernels.hip — hand-written gfx950 (CDNA4) kernels of the GP engine and their launchers.
+//
+//  gemm_kernel   : MFMA tile GEMM with triangular contraction ranges; carries Cholesky TRSM/SYRK, the
+//                  triangular inverse (TRTRI as GEMMs), LAUUM (K^-1 = X^T X) and the predictive GEMM.
+//  leaf_kernel   : 128x128 diagonal block: Cholesky + inverse of the factor, LDS resident, 16x16 diagonal
+//                  sub-blocks factored in one wavefront with lane broadcasts, the rest on MFMA.
+//  kmat_kernel   : K = c*Matern(X,X) + s2*I (lower tiles), matern_kernel.rs:37-81 + constant/product kernels + lml.rs:44.
+//  gradtrace     : 1/2 tr((aa^T - K^-1) dK/dtheta_j) for all j in one pass over K^-1 (lml.rs:62-70, matern_kernel.rs:83-135)
+//                  without the n x n x (d+1) tensor the reference materialises.
+//  trmv/finalize : alpha = X^T (X y), y^T alpha, sum log L_ii (lml.rs:54-59).
+//  kstar/pred_*  : predict.rs:7-52.
+//
+// Element type T is double or float; MFMA = v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32
+// (A frag: lane l holds A[l&15][l>>4]; B frag: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4)+4r for f64,
+//  4*(l>>4)+r for f32).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "engine.hpp"
+
+namespace hbegp {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Cfg;
+template <> struct Cfg<double> {
+  static constexpr int VEC = 2;   // elements per 16-byte chunk
+  static constexpr int BK = 16;   // contraction depth per LDS stage (128 bytes)
+  using vec_t = d2;
+  using acc_t = d4;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+  static __device__ __forceinline__ void lds_store(double* dst, vec_t v) { *reinterpret_cast<vec_t*>(dst) = v; }
+};
+template <> struct Cfg<float> {
+  static constexpr int VEC = 4;
+  static constexpr int BK = 32;
+  using vec_t = f4;
+  using acc_t = f4;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) * 4 + r; }
+  static __device__ __forceinline__ void lds_store(float* dst, vec_t v) {  // rows are only 8-byte aligned
+    f2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+    *reinterpret_cast<f2*>(dst) = lo;
+    *reinterpret_cast<f2*>(dst + 2) = hi;
+  }
+};
+
+__device__ __forceinline__ double readlane(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// =================================================================================================================
+// Tile GEMM
+// =================================================================================================================
+template <typename T, int TILE>
+struct GemmGeom {
+  using C = Cfg<T>;
+  static constexpr int SK = C::BK + 2;        // LDS row stride, operand stored [outer][k]
+  static constexpr int SM = TILE + 16;        // LDS row stride, operand stored [k][outer]
+  static constexpr int LDSE = (TILE * SK > C::BK * SM) ? TILE * SK : C::BK * SM;  // elements per operand buffer
+  static constexpr int NCH = TILE / 32;       // 16-byte chunks per thread per operand per stage
+  static constexpr int TM = TILE / 32;        // 16x16 MFMA blocks per wave per dimension
+  static constexpr int SPT = TILE / C::BK;    // stages per contraction tile
+};
+
+__device__ __forceinline__ int tri_row(int idx) {
+  // largest r with r(r+1)/2 <= idx
+  int r = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+  while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+  while (r * (r + 1) / 2 > idx) --r;
+  return r;
+}
+
+template <typename T, int TILE>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
+  using C = Cfg<T>;
+  using G = GemmGeom<T, TILE>;
+  using vec_t = typename C::vec_t;
+  using acc_t = typename C::acc_t;
+  constexpr int VEC = C::VEC, BK = C::BK, SK = G::SK, SM = G::SM, NCH = G::NCH, TM = G::TM, SPT = G::SPT;
+
+  if (*g.info != 0) return;
+
+  int bid = blockIdx.x;
+  int oi = 0;
+  if (g.nops > 1 && bid >= g.op[0].ntiles) {
+    oi = 1;
+    bid -= g.op[0].ntiles;
+  }
+  const GemmOp& op = g.op[oi];
+
+  int li, lj;
+  if (op.c_lower) {
+    li = tri_row(bid);
+    lj = bid - li * (li + 1) / 2;
+  } else {
+    li = bid / op.nj;
+    lj = bid - li * op.nj;
+  }
+  const int ti = op.ci0 + li, tj = op.cj0 + lj;
+
+  int ka = op.k0, kb = op.k1;
+  switch (op.klim) {
+    case 1: kb = min(kb, tj + 1); break;
+    case 2: ka = max(ka, tj); break;
+    case 3: kb = min(kb, ti + 1); break;
+    case 4: ka = max(ka, ti); break;
+    default: break;
+  }
+  const int nstages = (kb - ka) * SPT;
+
+  extern __shared__ __align__(16) char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);  // [A buf0 | A buf1 | B buf0 | B buf1], LDSE elements each
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int akm = op.a_kmajor, bkm = op.b_kmajor;
+  const int lda = op.lda, ldb = op.ldb;
+
+  // Per-thread chunk 0 of a stage slab: storage (row, col) relative to the slab origin; chunk q = chunk 0 + q row passes.
+  constexpr int CPR = TILE / VEC;        // chunks per slab row, operand stored [k][outer]
+  constexpr int RPP_K = 32;              // slab rows covered per pass, operand stored [outer][k] (8 chunks per row)
+  constexpr int RPP_M = 256 / CPR;       // slab rows covered per pass, operand stored [k][outer]
+  const int a_r0 = akm ? t / CPR : t >> 3, a_c0 = akm ? (t % CPR) * VEC : (t & 7) * VEC;
+  const int b_r0 = bkm ? t / CPR : t >> 3, b_c0 = bkm ? (t % CPR) * VEC : (t & 7) * VEC;
+  const int a_rpp = akm ? RPP_M : RPP_K, b_rpp = bkm ? RPP_M : RPP_K;
+  const int a_lds0 = a_r0 * (akm ? SM : SK) + a_c0, a_ldsq = a_rpp * (akm ? SM : SK);
+  const int b_lds0 = 2 * G::LDSE + b_r0 * (bkm ? SM : SK) + b_c0, b_ldsq = b_rpp * (bkm ? SM : SK);
+
+  // global pointers of chunk 0 at stage 0; they advance by a uniform stride per stage
+  const T* pA = static_cast<const T*>(op.A) +
+                (akm ? (size_t)(ka * TILE + a_r0) * lda + ti * TILE + a_c0 : (size_t)(ti * TILE + a_r0) * lda + ka * TILE + a_c0);
+  const T* pB = static_cast<const T*>(op.B) +
+                (bkm ? (size_t)(ka * TILE + b_r0) * ldb + tj * TILE + b_c0 : (size_t)(tj * TILE + b_r0) * ldb + ka * TILE + b_c0);
+  const size_t a_step = akm ? (size_t)BK * lda : (size_t)BK, b_step = bkm ? (size_t)BK * ldb : (size_t)BK;
+  const size_t a_qs = (size_t)a_rpp * lda, b_qs = (size_t)b_rpp * ldb;
+
+  vec_t ra[NCH], rb[NCH];
+
+  auto load_stage = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) ra[q] = *reinterpret_cast<const vec_t*>(pA + q * a_qs);
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) rb[q] = *reinterpret_cast<const vec_t*>(pB + q * b_qs);
+    pA += a_step;
+    pB += b_step;
+    const int tk = ka + s / SPT;
+    if ((op.maskA && tk == ti) || (op.maskB && tk == tj)) {  // storage-diagonal tile of a triangular operand (uniform branch)
+      const int kk = tk * TILE + (s % SPT) * BK;
+      if (op.maskA && tk == ti) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+          const int gr = (akm ? kk : ti * TILE) + a_r0 + q * a_rpp, gc = (akm ? ti * TILE : kk) + a_c0;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (gc + e > gr) ra[q][e] = 0;
+        }
+      }
+      if (op.maskB && tk == tj) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+          const int gr = (bkm ? kk : tj * TILE) + b_r0 + q * b_rpp, gc = (bkm ? tj * TILE : kk) + b_c0;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            if (gc + e > gr) rb[q][e] = 0;
+        }
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      C::lds_store(lds + buf * G::LDSE + a_lds0 + q * a_ldsq, ra[q]);
+      C::lds_store(lds + buf * G::LDSE + b_lds0 + q * b_ldsq, rb[q]);
+    }
+  };
+
+  acc_t acc[TM][TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+
+  // fragment addressing: element (outer index o, contraction k) at o*so + k*sk
+  const int soA = akm ? 1 : SK, skA = akm ? SM : 1;
+  const int soB = bkm ? 1 : SK, skB = bkm ? SM : 1;
+  const int fa0 = (wm * (TILE / 2) + (lane & 15)) * soA + (lane >> 4) * skA;
+  const int fb0 = 2 * G::LDSE + (wn * (TILE / 2) + (lane & 15)) * soB + (lane >> 4) * skB;
+
+  if (nstages > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nstages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstages) load_stage(s + 1);
+    const int ia = buf * G::LDSE + fa0, ib = buf * G::LDSE + fb0;
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4) {
+      T af[TM], bf[TM];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = lds[ia + a * 16 * soA + k4 * 4 * skA];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) bf[b] = lds[ib + b * 16 * soB + k4 * 4 * skB];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = C::mfma(af[a], bf[b], acc[a][b]);
+    }
+    if (s + 1 < nstages) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+  T* Cg = static_cast<T*>(op.C);
+  const int row0 = ti * TILE + wm * (TILE / 2), col0 = tj * TILE + wn * (TILE / 2) + (lane & 15);
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + a * 16 + C::crow(lane, r);
+        T* p = Cg + (size_t)row * op.ldc + col0 + b * 16;
+        T v = acc[a][b][r];
+        if (op.alpha_neg) v = -v;
+        if (op.beta_one) v += *p;
+        *p = v;
+      }
+}
+
+template <typename T, int TILE>
+static void launch_gemm_t(const GemmLaunch& gl, hipStream_t s) {
+  using G = GemmGeom<T, TILE>;
+  GemmLaunch g = gl;
+  int total = 0;
+  for (int i = 0; i < g.nops; ++i) {
+    GemmOp& op = g.op[i];
+    op.ntiles = op.c_lower ? op.mi * (op.mi + 1) / 2 : op.mi * op.nj;
+    total += op.ntiles;
+  }
+  if (total <= 0) return;
+  const size_t lds = (size_t)4 * G::LDSE * sizeof(T);
+  hipLaunchKernelGGL((gemm_kernel<T, TILE>), dim3(total), dim3(256), lds, s, g);
+}
+
+// ops are specified in NB(=128)-tile units by the host; rescale to the launch tile size here.
+template <typename T>
+void launch_gemm(const GemmLaunch& gl, int tile, hipStream_t s) {
+  GemmLaunch g = gl;
+  const int f = NB / tile;
+  for (int i = 0; i < g.nops; ++i) {
+    GemmOp& op = g.op[i];
+    op.ci0 *= f; op.cj0 *= f; op.mi *= f; op.nj *= f; op.k0 *= f; op.k1 *= f;
+  }
+  if (tile == 128) launch_gemm_t<T, 128>(g, s);
+  else if (tile == 64) launch_gemm_t<T, 64>(g, s);
+  else launch_gemm_t<T, 32>(g, s);
+}
+template void launch_gemm<double>(const GemmLaunch&, int, hipStream_t);
+template void launch_gemm<float>(const GemmLaunch&, int, hipStream_t);
+
+// =================================================================================================================
+// Leaf: 128x128 diagonal block.  L = chol(A) (lower), X = L^-1.
+// =================================================================================================================
+template <typename T>
+struct LeafGeom {
+  static constexpr int S = 130;          // LDS row stride of the block image
+  static constexpr int YS = 18;          // row stride of a 16x16 sub-block image
+  static constexpr int YB = 16 * YS;     // elements per 16x16 image
+  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 8 * YB + 4 * YB) * sizeof(T);
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __restrict__ W2, int ld, int blk,
+                                                   T* __restrict__ ldiag, int* info) {
+  using C = Cfg<T>;
+  using L = LeafGeom<T>;
+  using acc_t = typename C::acc_t;
+  using vec_t = typename C::vec_t;
+  constexpr int S = L::S, YS = L::YS, YB = L::YB, VEC = C::VEC;
+  if (*info != 0) return;
+
+  extern __shared__ __align__(16) char smem_raw[];
+  T* As = reinterpret_cast<T*>(smem_raw);  // [128][S]: lower = A -> L ; strict upper blocks = X^T
+  T* Ys = As + 128 * S;                    // [8][16][YS]: inverses of the diagonal 16x16 factors
+  T* Sc = Ys + 8 * YB;                     // [4][16][YS]: per-wave scratch
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m16 = lane & 15, q4 = lane >> 4;
+  const size_t g0 = (size_t)blk * NB * ld + (size_t)blk * NB;
+  T* Ablk = W1 + g0;
+  T* Xblk = W2 + g0;
+
+  // load the block (coalesced 16-byte chunks)
+  for (int c = t; c < 128 * (128 / VEC); c += 256) {
+    const int r = c / (128 / VEC), cc = (c % (128 / VEC)) * VEC;
+    vec_t v = *reinterpret_cast<const vec_t*>(Ablk + (size_t)r * ld + cc);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = v[e];
+  }
+  __syncthreads();
+
+  // ---------------- phase 1: blocked right-looking Cholesky, 16-wide panels ----------------
+  for (int p = 0; p < 8; ++p) {
+    if (wave == 0) {
+      // 16x16 diagonal block: lane r (and its 3 replicas) owns row r of [A | I]; forward elimination gives L and L^-1.
+      const int r = m16;
+      T a[16], yv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        a[j] = As[(p * 16 + r) * S + p * 16 + j];
+        yv[j] = (j == r) ? T(1) : T(0);
+      }
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const T piv = readlane(a[k], k);
+        if (!(piv > T(0))) bad = true;
+        const T rinv = T(1) / sqrt(piv);
+        const T lk = a[k] * rinv;  // l_{r,k}
+        a[k] = lk;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) {
+          const T ljk = readlane(lk, j);
+          if (r > k) a[j] -= lk * ljk;
+        }
+#pragma unroll
+        for (int j = 0; j <= k; ++j) {
+          const T ykj = readlane(yv[j], k) * rinv;
+          if (r > k) yv[j] -= lk * ykj;
+          else if (r == k) yv[j] = ykj;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          if (j <= r) As[(p * 16 + r) * S + p * 16 + j] = a[j];
+          Ys[p * YB + r * YS + j] = (j <= r) ? yv[j] : T(0);
+        }
+        T dv = T(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j == r) dv = a[j];
+        ldiag[blk * NB + p * 16 + r] = dv;
+      }
+      if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
+    }
+    __syncthreads();
+
+    // panel: L[i,p] = A[i,p] * Y_pp^T, i > p
+    for (int i = p + 1 + wave; i < 8; i += 4) {
+      acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const T af = As[(i * 16 + m16) * S + p * 16 + k4 * 4 + q4];
+        const T bf = Ys[p * YB + m16 * YS + k4 * 4 + q4];
+        acc = C::mfma(af, bf, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) As[(i * 16 + C::crow(lane, r)) * S + p * 16 + m16] = acc[r];
+    }
+    __syncthreads();
+
+    // trailing update inside the block: A[i,j] -= L[i,p] L[j,p]^T, p < j <= i
+    {
+      const int tcount = 7 - p;
+      const int nblk = tcount * (tcount + 1) / 2;
+      for (int idx = wave; idx < nblk; idx += 4) {
+        const int li = tri_row(idx), lj = idx - li * (li + 1) / 2;
+        const int i = p + 1 + li, j = p + 1 + lj;
+        acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const T af = As[(i * 16 + m16) * S + p * 16 + k4 * 4 + q4];
+          const T bf = As[(j * 16 + m16) * S + p * 16 + k4 * 4 + q4];
+          acc = C::mfma(af, bf, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T* pc = &As[(i * 16 + C::crow(lane, r)) * S + j * 16 + m16];
+          *pc = *pc - acc[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- phase 2: X = L^-1 by block sub-diagonals ----------------
+  // X[i,i] = Y_ii ; X[i,j] = -Y_ii * sum_{k=j}^{i-1} L[i,k] X[k,j].  X[k,j] (k>j) is kept transposed in the upper part of As.
+  T* sc = Sc + wave * YB;
+  for (int sd = 1; sd < 8; ++sd) {
+    for (int j = wave; j + sd < 8; j += 4) {
+      const int i = j + sd;
+      acc_t acc = {0, 0, 0, 0};
+      for (int k = j; k < i; ++k) {
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const T af = As[(i * 16 + m16) * S + k * 16 + k4 * 4 + q4];
+          T bf;
+          if (k == j) bf = Ys[j * YB + (k4 * 4 + q4) * YS + m16];
+          else bf = As[(j * 16 + m16) * S + k * 16 + k4 * 4 + q4];
+          acc = C::mfma(af, bf, acc);
+        }
+      }
+      // stage S through wave-private LDS to re-read it as a B operand
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[C::crow(lane, r) * YS + m16] = acc[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      acc_t res = {0, 0, 0, 0};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const T af = Ys[i * YB + m16 * YS + k4 * 4 + q4];
+        const T bf = sc[(k4 * 4 + q4) * YS + m16];
+        res = C::mfma(af, bf, res);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = C::crow(lane, r);
+        const T v = -res[r];
+        As[(j * 16 + m16) * S + i * 16 + row] = v;                       // transposed copy for later products
+        Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16] = v;            // X[i,j]
+      }
+    }
+    __syncthreads();
+  }
+  // diagonal sub-blocks of X
+  for (int c = t; c < 8 * 256; c += 256) {
+    const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
+    Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j] = Ys[pblk * YB + r * YS + j];
+  }
+}
+
+template <typename T>
+void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s) {
+  hipLaunchKernelGGL((leaf_kernel<T>), dim3(1), dim3(256), LeafGeom<T>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info);
+}
+template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t);
+template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t);
+
+// =================================================================================================================
+// Kernel-matrix assembly
+// =================================================================================================================
+// Matern map of matern_kernel.rs:65-80; nu2 = 2*nu in {1,3,5}; r = euclidean distance of length-scaled points.
+template <typename T>
+__device__ __forceinline__ T matern_map(T r, int nu2) {
+  if (nu2 == 1) return exp(-r);
+  if (nu2 == 3) {
+    const T k = r * T(1.7320508075688772);
+    return (k + T(1)) * exp(-k);
+  }
+  const T k = r * T(2.23606797749979);
+  return (T(1) + k + k * k / T(3)) * exp(-k);
+}
+
+// 64x64 tile per workgroup; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.
+template <typename T>
+__global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int n, int d, int np, int nu2,
+                                                   const EvalParams* __restrict__ P, T* __restrict__ W,
+                                                   const int* info) {
+  if (*info != 0) return;
+  extern __shared__ __align__(16) char smem_raw[];
+  T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] scaled rows of the i tile (feature-major)
+  T* xj = xi + (size_t)d * 64;             // [d][64]
+  const int li = tri_row(blockIdx.x), lj = blockIdx.x - li * (li + 1) / 2;
+  const int i0 = li * 64, j0 = lj * 64;
+  const int t = threadIdx.x;
+  for (int e = t; e < 64 * d; e += 256) {
+    const int row = e / d, k = e - row * d;
+    const T ell = (T)P->ell[k];  // A::from_f (matern_kernel.rs:50)
+    const int gi = i0 + row, gj = j0 + row;
+    xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] / ell : T(0);  // matern_kernel.rs:51-60
+    xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
+  }
+  __syncthreads();
+  const int tx = t & 15, ty = t >> 4;
+  T acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
+  for (int k = 0; k < d; ++k) {  // cdist accumulation order (matern_kernel.rs:274-278)
+    T a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T df = a[r] - b[c];
+        acc[r][c] += df * df;
+      }
+  }
+  const T amp = (T)P->amp, noise = (T)P->noise;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = i0 + ty + 16 * r;
+    T out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gj = j0 + tx * 4 + c;
+      T v;
+      if (gi < n && gj < n) {
+        v = amp * matern_map<T>(sqrt(acc[r][c]), nu2);  // product_kernel.rs:37 (k1 * k2)
+        if (gi == gj) v += noise;                        // lml.rs:44
+      } else {
+        v = (gi == gj) ? T(1) : T(0);                    // identity padding
+      }
+      out[c] = v;
+    }
+    T* p = W + (size_t)gi * np + j0 + tx * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p[c] = out[c];
+  }
+}
+
+template <typename T>
+void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s) {
+  const int nt = np / 64;
+  const size_t lds = (size_t)2 * d * 64 * sizeof(T);
+  hipLaunchKernelGGL((kmat_kernel<T>), dim3(nt * (nt + 1) / 2), dim3(256), lds, s, X, n, d, np, nu2, P, W, info);
+}
+template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t);
+template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t);
+
+// =================================================================================================================
+// alpha = K^-1 y through the explicit inverse factor: w = X y, alpha = X^T w;  lml pieces (lml.rs:54-59)
+// =================================================================================================================
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+// block sum for 256 threads; result valid in thread 0. red: >= 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// one wave per row: w_i = sum_{k<=i} X[i][k] y[k]
+template <typename T>
+__global__ void __launch_bounds__(256) trmv_n_kernel(const T* __restrict__ Xinv, int np, int n, const T* __restrict__ y,
+                                                     T* __restrict__ w, const int* info) {
+  if (*info != 0) return;
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= np) return;
+  double acc = 0;
+  const T* xr = Xinv + (size_t)row * np;
+  for (int k = lane; k <= row && k < n; k += 64) acc += (double)xr[k] * (double)y[k];
+  acc = wave_sum(acc);
+  if (lane == 0) w[row] = (T)acc;
+}
+
+// partial[chunk][j] = sum_{i in chunk, i>=j} X[i][j] w[i]; chunk = 256 rows; 64 columns per workgroup
+template <typename T>
+__global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv, int np, const T* __restrict__ w,
+                                                     double* __restrict__ part, const int* info) {
+  if (*info != 0) return;
+  __shared__ double red[4][64];
+  const int c = threadIdx.x & 63, sgrp = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c, chunk = blockIdx.y;
+  double acc = 0;
+  const int i_begin = chunk * 256, i_end = min(i_begin + 256, np);
+  if (i_end > blockIdx.x * 64) {
+    for (int i = i_begin + sgrp; i < i_end; i += 4)
+      if (i >= j) acc += (double)Xinv[(size_t)i * np + j] * (double)w[i];
+  }
+  red[sgrp][c] = acc;
+  __syncthreads();
+  if (sgrp == 0) part[(size_t)chunk * np + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) finalize_lml_kernel(const double* __restrict__ part, int nchunks, int np, int n,
+                                                           const T* __restrict__ y, const T* __restrict__ ldiag,
+                                                           T* __restrict__ alpha, EvalOut* out, const int* info) {
+  if (*info != 0) return;
+  __shared__ double red[4];
+  double ya = 0, ld = 0;
+  for (int j = threadIdx.x; j < np; j += 256) {
+    double a = 0;
+    for (int c = j / 256; c < nchunks; ++c) a += part[(size_t)c * np + j];
+    const T at = (T)a;
+    alpha[j] = (j < n) ? at : T(0);
+    if (j < n) {
+      ya += (double)y[j] * (double)at;
+      ld += log((double)ldiag[j]);
+    }
+  }
+  const double s1 = block_sum(ya, red);
+  const double s2 = block_sum(ld, red);
+  if (threadIdx.x == 0) {
+    out->yalpha = s1;
+    out->logdet = s2;
+    out->lml = -0.5 * s1 - s2 - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);  // lml.rs:57-59
+  }
+}
+
+template <typename T>
+void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, T* wbuf, double* part, T* alpha,
+                      EvalOut* out, const int* info, hipStream_t s) {
+  hipLaunchKernelGGL((trmv_n_kernel<T>), dim3(np / 4), dim3(256), 0, s, Xinv, np, n, y, wbuf, info);
+  const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
+  hipLaunchKernelGGL((trmv_t_kernel<T>), dim3(np / 64, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info);
+  hipLaunchKernelGGL((finalize_lml_kernel<T>), dim3(1), dim3(256), 0, s, part, nchunks, np, n, y, ldiag, alpha, out, info);
+}
+template void launch_alpha_lml<double>(const double*, int, int, const double*, const double*, double*, double*, double*,
+                                       EvalOut*, const int*, hipStream_t);
+template void launch_alpha_lml<float>(const float*, int, int, const float*, const float*, float*, double*, float*,
+                                      EvalOut*, const int*, hipStream_t);
+
+// =================================================================================================================
+// Gradient of the lml: g_j = 1/2 sum_ik (alpha_i alpha_k - Kinv_ik) dK_ik/dtheta_j   (lml.rs:62-70)
+// theta order [noise, amplitude, ell_1..ell_d]; dK formulas: constant_kernel.rs:31-38, product_kernel.rs:56-67,
+// matern_kernel.rs:88-131.  One pass over the lower triangle of Kinv (off-diagonal entries weighted twice).
+// =================================================================================================================
+constexpr int GT_CHUNK = 8;  // length-scale parameters accumulated per register pass
+
+template <typename T>
+__global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np, int nu2,
+                                                        const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
+                                                        const T* __restrict__ alpha, double* __restrict__ part,
+                                                        const int* info) {
+  if (*info != 0) return;
+  extern __shared__ __align__(16) char smem_raw[];
+  T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] raw features of the i tile
+  T* xj = xi + (size_t)d * 64;
+  __shared__ double red[4];
+  __shared__ double inv_l2[MAXD];
+  const int li = tri_row(blockIdx.x), lj = blockIdx.x - li * (li + 1) / 2;
+  const int i0 = li * 64, j0 = lj * 64;
+  const int t = threadIdx.x;
+  for (int e = t; e < 64 * d; e += 256) {
+    const int row = e / d, k = e - row * d;
+    const int gi = i0 + row, gj = j0 + row;
+    xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] : T(0);
+    xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] : T(0);
+  }
+  if (t < d) {
+    const T ell = (T)P->ell[t];
+    inv_l2[t] = (double)(T(1) / (ell * ell));  // 1/scales_k_square (matern_kernel.rs:94-98)
+  }
+  __syncthreads();
+  const int tx = t & 15, ty = t >> 4;
+  const T amp = (T)P->amp, noise = (T)P->noise;
+
+  // pass A: per-element coefficient coef = wgt * W * c * g(r) and the noise / amplitude sums
+  T coef[4][4];
+  double g_noise = 0, g_amp = 0;
+  {
+    T dsum[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dsum[r][c] = T(0);
+    for (int k = 0; k < d; ++k) {
+      const T il2 = (T)inv_l2[k];
+      T a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const T df = a[r] - b[c];
+          dsum[r][c] += df * df * il2;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = i0 + ty + 16 * r;
+      const T ai = (gi < n) ? alpha[gi] : T(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gj = j0 + tx * 4 + c;
+        T cf = T(0);
+        if (gi < n && gj <= gi) {
+          const T w = ai * alpha[gj] - Kinv[(size_t)gi * np + gj];  // lml.rs:62 (tmp)
+          const T wgt = (gi == gj) ? T(1) : T(2);
+          const T ds = dsum[r][c];
+          T km, gr;  // Matern value and gradient factor g(r) with dK/dlog(ell_k) = c * g * d_k
+          if (nu2 == 5) {
+            const T tt = sqrt(ds * T(5));
+            const T e = exp(-tt);
+            km = (T(1) + tt + tt * tt / T(3)) * e;
+            gr = T(5.0 / 3.0) * (tt + T(1)) * e;  // matern_kernel.rs:119-131
+          } else if (nu2 == 3) {
+            const T tt = sqrt(ds * T(3));
+            const T e = exp(-tt);
+            km = (tt + T(1)) * e;
+            gr = T(3) * e;  // matern_kernel.rs:112-118
+          } else {
+            const T rr = sqrt(ds);
+            km = exp(-rr);
+            gr = (rr > T(0)) ? km / rr : T(0);  // matern_kernel.rs:102-111 (non-finite -> 0)
+          }
+          if (gi == gj) g_noise += (double)(w * noise);      // noise gradient = eye * noise (lml.rs:41)
+          g_amp += (double)(wgt * w * (amp * km));            // constant_kernel.rs:31-38 x K_matern
+          cf = wgt * w * amp * gr;
+        }
+        coef[r][c] = cf;
+      }
+    }
+  }
+  const int p = d + 2;
+  double* my = part + (size_t)blockIdx.x * p;
+  {
+    const double s0 = block_sum(g_noise, red);
+    const double s1 = block_sum(g_amp, red);
+    if (t == 0) {
+      my[0] = s0;
+      my[1] = s1;
+    }
+  }
+  // pass B: length-scale gradients, GT_CHUNK parameters at a time
+  for (int kc = 0; kc < d; kc += GT_CHUNK) {
+    double acc[GT_CHUNK];
+#pragma unroll
+    for (int u = 0; u < GT_CHUNK; ++u) acc[u] = 0;
+#pragma unroll
+    for (int u = 0; u < GT_CHUNK; ++u) {
+      const int k = kc + u;
+      if (k < d) {
+        const T il2 = (T)inv_l2[k];
+        T a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+        T sacc = T(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const T df = a[r] - b[c];
+            sacc += coef[r][c] * (df * df * il2);
+          }
+        acc[u] = (double)sacc;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GT_CHUNK; ++u) {
+      const int k = kc + u;
+      if (k < d) {  // uniform
+        const double sres = block_sum(acc[u], red);
+        if (t == 0) my[2 + k] = sres;
+      }
+    }
+  }
+}
+
+// grad[j] = 0.5 * sum_blocks part[b][j]  (fixed summation order -> bitwise reproducible)
+__global__ void __launch_bounds__(256) finalize_grad_kernel(const double* __restrict__ part, int nblocks, int p,
+                                                            EvalOut* out, const int* info) {
+  if (*info != 0) return;
+  __shared__ double red[4];
+  const int j = blockIdx.x;
+  double acc = 0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) acc += part[(size_t)b * p + j];
+  const double s = block_sum(acc, red);
+  if (threadIdx.x == 0) out->grad[j] = 0.5 * s;
+}
+
+size_t gradtrace_part_elems(int np, int d) {
+  const int nt = np / 64;
+  return (size_t)(nt * (nt + 1) / 2) * (d + 2);
+}
+
+template <typename T>
+void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
+                      double* part, EvalOut* out, const int* info, hipStream_t s) {
+  const int nt = np / 64;
+  const int nblocks = nt * (nt + 1) / 2;
+  const size_t lds = (size_t)2 * d * 64 * sizeof(T);
+  hipLaunchKernelGGL((gradtrace_kernel<T>), dim3(nblocks), dim3(256), lds, s, X, n, d, np, nu2, P, Kinv, alpha, part, info);
+  hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, nblocks, d + 2, out, info);
+}
+template void launch_gradtrace<double>(const double*, int, int, int, int, const EvalParams*, const double*, const double*,
+                                       double*, EvalOut*, const int*, hipStream_t);
+template void launch_gradtrace<float>(const float*, int, int, int, int, const EvalParams*, const float*, const float*,
+                                      double*, EvalOut*, const int*, hipStream_t);
+
+// =================================================================================================================
+// symmetrize: mirror the lower triangle into the upper one (what invc() hands back, lml.rs:62)
+// =================================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) symmetrize_kernel(T* __restrict__ A, int np) {
+  __shared__ T tile[64][65];
+  const int li = tri_row(blockIdx.x), lj = blockIdx.x - li * (li + 1) / 2;
+  const int i0 = li * 64, j0 = lj * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) tile[r][tx] = A[(size_t)(i0 + r) * np + j0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    // element (j0+r, i0+tx) = A[i0+tx][j0+r]
+    if (li != lj || tx > r) A[(size_t)(j0 + r) * np + i0 + tx] = tile[tx][r];
+  }
+}
+template <typename T>
+void launch_symmetrize(T* A, int np, hipStream_t s) {
+  const int nt = np / 64;
+  hipLaunchKernelGGL((symmetrize_kernel<T>), dim3(nt * (nt + 1) / 2), dim3(256), 0, s, A, np);
+}
+template void launch_symmetrize<double>(double*, int, hipStream_t);
+template void launch_symmetrize<float>(float*, int, hipStream_t);
+
+// =================================================================================================================
+// predict (predict.rs:7-52)
+// =================================================================================================================
+// Kstar[mp][np]: row = candidate.  64x64 tiles as in kmat, no noise, zero padding.
+template <typename T>
+__global__ void __launch_bounds__(256) kstar_kernel(const T* __restrict__ Xs, int m, const T* __restrict__ X, int n, int d,
+                                                    int np, int nu2, const EvalParams* __restrict__ P, T* __restrict__ Ks) {
+  extern __shared__ __align__(16) char smem_raw[];
+  T* xi = reinterpret_cast<T*>(smem_raw);
+  T* xj = xi + (size_t)d * 64;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  for (int e = t; e < 64 * d; e += 256) {
+    const int row = e / d, k = e - row * d;
+    const T ell = (T)P->ell[k];
+    const int gi = i0 + row, gj = j0 + row;
+    xi[k * 64 + row] = (gi < m) ? Xs[(size_t)gi * d + k] / ell : T(0);
+    xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
+  }
+  __syncthreads();
+  const int tx = t & 15, ty = t >> 4;
+  T acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
+  for (int k = 0; k < d; ++k) {
+    T a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T df = a[r] - b[c];
+        acc[r][c] += df * df;
+      }
+  }
+  const T amp = (T)P->amp;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = i0 + ty + 16 * r;
+    T* p = Ks + (size_t)gi * np + j0 + tx * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gj = j0 + tx * 4 + c;
+      p[c] = (gi < m && gj < n) ? amp * matern_map<T>(sqrt(acc[r][c]), nu2) : T(0);
+    }
+  }
+}
+template <typename T>
+void launch_kstar(const T* Xs, int m, int mp, const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* Ks,
+                  hipStream_t s) {
+  const size_t lds = (size_t)2 * d * 64 * sizeof(T);
+  hipLaunchKernelGGL((kstar_kernel<T>), dim3(np / 64, mp / 64), dim3(256), lds, s, Xs, m, X, n, d, np, nu2, P, Ks);
+}
+template void launch_kstar<double>(const double*, int, int, const double*, int, int, int, int, const EvalParams*, double*,
+                                   hipStream_t);
+template void launch_kstar<float>(const float*, int, int, const float*, int, int, int, int, const EvalParams*, float*,
+                                  hipStream_t);
+
+// mean_k = sum_j Kstar[k][j] alpha[j]  (predict.rs:19); one wave per candidate
+template <typename T>
+__global__ void __launch_bounds__(256) pred_mean_kernel(const T* __restrict__ Ks, int m, int np, const T* __restrict__ alpha,
+                                                        T* __restrict__ mean) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  double acc = 0;
+  const T* kr = Ks + (size_t)row * np;
+  for (int j = lane; j < np; j += 64) acc += (double)kr[j] * (double)alpha[j];
+  acc = wave_sum(acc);
+  if (lane == 0) mean[row] = (T)acc;
+}
+template <typename T>
+void launch_pred_mean(const T* Ks, int m, int np, const T* alpha, T* mean, hipStream_t s) {
+  hipLaunchKernelGGL((pred_mean_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, s, Ks, m, np, alpha, mean);
+}
+template void launch_pred_mean<double>(const double*, int, int, const double*, double*, hipStream_t);
+template void launch_pred_mean<float>(const float*, int, int, const float*, float*, hipStream_t);
+
+// var_k = c + 1e-5 - sum_j Q[k][j] Kstar[k][j], clamp negatives, count those below -sqrt(1e-5)  (predict.rs:25-48)
+template <typename T>
+__global__ void __launch_bounds__(256) pred_var_kernel(const T* __restrict__ Ks, const T* __restrict__ Q, int m, int np,
+                                                       const EvalParams* __restrict__ P, T* __restrict__ var, EvalOut* out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  double acc = 0;
+  const T* kr = Ks + (size_t)row * np;
+  const T* qr = Q + (size_t)row * np;
+  for (int j = lane; j < np; j += 64) acc += (double)kr[j] * (double)qr[j];
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const T min_noise = (T)1e-5;
+    T v = (T)P->amp + min_noise - (T)acc;
+    if (v < -sqrt(min_noise)) atomicAdd(&out->n_warn, 1);
+    if (v < T(0)) v = T(0);
+    var[row] = v;
+  }
+}
+template <typename T>
+void launch_pred_var(const T* Ks, const T* Q, int m, int np, const EvalParams* P, T* var, EvalOut* out, hipStream_t s) {
+  hipLaunchKernelGGL((pred_var_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, s, Ks, Q, m, np, P, var, out);
+}
+template void launch_pred_var<double>(const double*, const double*, int, int, const EvalParams*, double*, EvalOut*, hipStream_t);
+template void launch_pred_var<float>(const float*, const float*, int, int, const EvalParams*, float*, EvalOut*, hipStream_t);
+
+// Per-device one-time setup: kernels that use more than 64 KiB of dynamic LDS need the attribute raised.  Called from
+// hbegp_ctx_create() for every device, before any stream capture.
+template <typename T, int TILE>
+static void init_gemm_attr() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((size_t)4 * GemmGeom<T, TILE>::LDSE * sizeof(T)));
+}
+void init_kernels() {
+  init_gemm_attr<double, 128>(); init_gemm_attr<double, 64>(); init_gemm_attr<double, 32>();
+  init_gemm_attr<float, 128>(); init_gemm_attr<float, 64>(); init_gemm_attr<float, 32>();
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LeafGeom<double>::LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LeafGeom<float>::LDS_BYTES);
+}
+
+__global__ void set_info_kernel(int* info, int value) { *info = value; }
+void launch_set_info(int* info, int value, hipStream_t s) { hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, s, info, value); }
+
+}  // namespace hbegp

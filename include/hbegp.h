@@ -1,0 +1,152 @@
+/*
+ * hbegp.h — C ABI of the MI355X-native Gaussian-process surrogate engine (libhbegp.so).
+ *
+ * Drop-in boundary for hbetune's `src/gpr` hot path.  The reference has no C ABI of its own; its seam
+ * is the pair of Rust traits `Estimator<A>` / `SurrogateModel<A>` (src/core/surrogate_model.rs:6-65),
+ * implemented for the CPU by `EstimatorGPR` / `SurrogateModelGPR<A>` (src/core/gpr.rs:54-63, 215-338),
+ * which call `FittedKernel::new/extend` (src/gpr/fit.rs:18-68) and `predict` (src/gpr/predict.rs:7-52).
+ * Every entry point below replaces one of those calls; the Rust-side binding a maintainer would add is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain C: host pointers and sizes only, no callbacks, no exceptions cross the boundary.
+ *   - Element type A is f64 (default) or f32 (`--use-32`, src/bin/hbetune/main.rs:240-244); entry points
+ *     that move arrays of A come in `_f64` / `_f32` pairs.  Hyper-parameters, bounds, lml and its
+ *     gradient are always f64 (src/gpr/lml.rs:9-10, src/util/bounded_value.rs).
+ *   - X is n x d row-major, features in [0,1] (src/core/space.rs:141-159); y has n entries and is
+ *     already y-normalised by the caller (src/core/ynormalize.rs stays in the adapter).
+ *   - Kernel = ConstantKernel(c) * Matern(nu, ell_1..ell_d) + white noise s2 (src/core/gpr.rs:51, 402-427),
+ *     nu in {0.5, 1.5, 2.5} (src/gpr/matern_kernel.rs:65-80).
+ *   - theta is log-space, p = d + 2 entries ordered [ln s2, ln c, ln ell_1 .. ln ell_d]
+ *     (src/gpr/fit.rs:140-144; gradient order src/gpr/lml.rs:67-68).  `lo`/`hi` are the linear-space
+ *     bounds in the same order.  Kernel parameters are clamped into their bounds after exp()
+ *     (`with_clamped_theta`, src/gpr/fit.rs:95); the noise is not (src/gpr/fit.rs:96).
+ *   - Return value: one of HBEGP_* below.  Negative = usage/runtime error (see hbegp_last_error()).
+ *   - All compute runs in hand-written HIP kernels on gfx950; there is no CPU fallback.  Without a GPU
+ *     hbegp_ctx_create() fails with HBEGP_ENODEV.
+ */
+#ifndef HBEGP_H
+#define HBEGP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HBEGP_VERSION 100 /* 0.1.0 */
+
+enum {
+  HBEGP_OK = 0,
+  HBEGP_NOT_PD = 1,     /* Cholesky failed: reference returns None -> objective +inf, gradient 0 (lml.rs:47-50, fit.rs:105-112) */
+  HBEGP_ALL_FAILED = 2, /* every evaluation of a fit failed: the reference would panic (fit.rs:161) */
+  HBEGP_EINVAL = -1,
+  HBEGP_EHIP = -2,      /* a HIP call failed */
+  HBEGP_ENODEV = -3,    /* no usable gfx950 device */
+  HBEGP_ENOMEM = -4
+};
+
+typedef struct hbegp_ctx hbegp_ctx;         /* devices, streams, workspace pools */
+typedef struct hbegp_problem hbegp_problem; /* X, y resident on the device(s) + evaluation workspaces */
+typedef struct hbegp_model hbegp_model;     /* fitted model: mirrors FittedKernel (fit.rs:6-12) + x_train */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int hbegp_version(void);
+/* Number of visible gfx950 devices (0 when there is none); does not initialise a context. */
+int hbegp_device_count(void);
+/* n_devices > 0; device_ids may be NULL (= 0..n_devices-1).  One process may own several GPUs: optimiser
+ * runs of one fit are sharded run r -> device r mod n_devices (restart axis, src/util/gradmin.rs:19-31). */
+int hbegp_ctx_create(int n_devices, const int* device_ids, hbegp_ctx** out);
+void hbegp_ctx_destroy(hbegp_ctx* ctx);
+/* Thread-local text of the last error raised through any handle (never NULL). */
+const char* hbegp_last_error(void);
+
+/* ---- problem: upload X, y once, evaluate many theta (the L-BFGS inner loop, fit.rs:93-134) ------- */
+/* n_slots >= 1 independent evaluation workspaces per device (one optimiser run uses one slot). */
+int hbegp_problem_create_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu,
+                             int n_slots, hbegp_problem** out);
+int hbegp_problem_create_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu,
+                             int n_slots, hbegp_problem** out);
+void hbegp_problem_destroy(hbegp_problem* prob);
+
+/* One evaluation of lml_with_gradient (src/gpr/lml.rs:29-79) on slot `slot` of device index `dev`.
+ * theta/lo/hi as above (lo/hi may be NULL = no clamping).  grad may be NULL (skips the gradient pass).
+ * Returns HBEGP_OK, or HBEGP_NOT_PD (then *lml = -inf and grad = 0). */
+int hbegp_problem_eval(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo,
+                       const double* hi, double* lml, double* grad);
+
+/* Copy out device results of the most recent successful evaluation on (dev, slot); any pointer may be NULL.
+ * alpha[n]; kinv[n*n] full symmetric row-major (what invc() returns, lml.rs:62); ldiag[n] = diag(L). */
+int hbegp_problem_get_f64(hbegp_problem* prob, int dev, int slot, double* alpha, double* kinv, double* ldiag);
+int hbegp_problem_get_f32(hbegp_problem* prob, int dev, int slot, float* alpha, float* kinv, float* ldiag);
+
+/* Kernel-matrix assembly only: K = c*Matern(X,X) + s2*I, full symmetric n*n row-major (lml.rs:40-44). */
+int hbegp_problem_kmat_f64(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo,
+                           const double* hi, double* K);
+int hbegp_problem_kmat_f32(hbegp_problem* prob, int dev, int slot, const double* theta, const double* lo,
+                           const double* hi, float* K);
+
+/* Timed evaluations for bench.py: runs `reps` evaluations at theta on (dev, slot) bracketed by hipEvents on the
+ * slot's stream.  phase_ms (may be NULL) receives per-phase averages measured with events in eager mode:
+ * [0] kmat, [1] chol+trtri GEMM launches (sum), [2] leaf (diag-block) launches (sum), [3] lauum GEMM,
+ * [4] alpha/lml reductions, [5] gradtrace, [6] whole evaluation (graph replay), [7] number of GEMM launches/eval. */
+int hbegp_problem_time_eval(hbegp_problem* prob, int dev, int slot, const double* theta, int reps,
+                            double* phase_ms);
+
+/* ---- fit / extend: mirrors FittedKernel::new / ::extend (fit.rs:18-68, 71-176) --------------------- */
+typedef struct hbegp_fit_options {
+  int maxeval;      /* evaluations per optimiser run; the reference uses 150 (gradmin.rs:54) */
+  int fixed_work;   /* 0: stop a run when the optimiser converges; 1: keep evaluating up to maxeval (bench) */
+  int lbfgs_memory; /* history pairs, 0 = default (10) */
+  int trace_cap;    /* capacity (in evaluations) of the trace buffers below, 0 = no trace */
+  /* optional trace of every evaluation in (run, eval) order, for replay parity against the oracle:
+   * trace_theta[trace_cap*p], trace_lml[trace_cap] (-inf when not PD), trace_grad[trace_cap*p], trace_run[trace_cap] */
+  double* trace_theta;
+  double* trace_lml;
+  double* trace_grad;
+  int* trace_run;
+  int* trace_count; /* out: number of evaluations recorded */
+} hbegp_fit_options;
+
+/* Maximise the log marginal likelihood over theta in [ln lo, ln hi] with 1 + n_restarts bounded L-BFGS runs:
+ * run 0 starts at theta0, run r>0 at starts[(r-1)*p .. ] (uniform draws in log-bounds made by the caller's RNG,
+ * gradmin.rs:22-24).  Capture rule = arg-max lml over every evaluation of every run (fit.rs:116-125), ties broken
+ * by the lowest (run, eval) index.  On success *model owns X, y, alpha, K^-1, theta_best (clamped, fit.rs:155-164).
+ * theta_best[p] and lml_best may be NULL.  Returns HBEGP_ALL_FAILED when no evaluation succeeded. */
+int hbegp_fit_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, const double* theta0,
+                  const double* lo, const double* hi, const double* starts, int n_restarts,
+                  const hbegp_fit_options* opt, double* theta_best, double* lml_best, hbegp_model** model);
+int hbegp_fit_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta0,
+                  const double* lo, const double* hi, const double* starts, int n_restarts,
+                  const hbegp_fit_options* opt, double* theta_best, double* lml_best, hbegp_model** model);
+
+/* One evaluation at fixed theta + K^-1 (fit.rs:33-68).  HBEGP_NOT_PD where the reference panics (fit.rs:55). */
+int hbegp_extend_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, const double* theta,
+                     const double* lo, const double* hi, hbegp_model** model);
+int hbegp_extend_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta,
+                     const double* lo, const double* hi, hbegp_model** model);
+
+/* ---- model: mirrors predict() (predict.rs:7-52) and the FittedKernel fields -------------------------- */
+/* mean[m]; var[m] or NULL.  var = c + 1e-5 - rowsum((K* K^-1) o K*), negatives clamped to 0 (predict.rs:25-48);
+ * it excludes s2 (the reference predicts the latent function).  *n_warn (may be NULL) = number of variances below
+ * -sqrt(1e-5) before clamping (the reference prints a warning for those, predict.rs:39-48). */
+int hbegp_predict_f64(hbegp_model* model, const double* Xs, int m, double* mean, double* var, int* n_warn);
+int hbegp_predict_f32(hbegp_model* model, const float* Xs, int m, float* mean, float* var, int* n_warn);
+
+int hbegp_model_info(const hbegp_model* model, int* n, int* d, int* is_f32, double* nu, double* lml);
+/* theta[p] (log space, clamped), alpha[n], kinv[n*n] full symmetric; any pointer may be NULL. */
+int hbegp_model_get_f64(hbegp_model* model, double* theta, double* alpha, double* kinv);
+int hbegp_model_get_f32(hbegp_model* model, double* theta, float* alpha, float* kinv);
+/* Reference counting for `Clone`/`Drop` of the Rust wrapper (gpr.rs:53; models are kept for the whole run,
+ * minimize.rs:331).  Device memory is freed on the last release. */
+void hbegp_model_retain(hbegp_model* model);
+void hbegp_model_release(hbegp_model* model);
+
+/* ---- host-side optimiser, exposed for its own tests (mirrors minimize_by_gradient, gradmin.rs:35-60) --------- */
+typedef double (*hbegp_objective_fn)(const double* x, double* grad, void* user);
+/* Bounded L-BFGS minimisation; x is updated in place; returns the best objective value found. */
+double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, const double* lo, const double* hi,
+                                  int n, int maxeval);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBEGP_H */

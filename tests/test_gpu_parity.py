@@ -1,0 +1,157 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the sklearn golden vectors.
+
+Tolerances (BASELINE.json north_star): f64 1e-8, f32 1e-4 — applied to the user-visible outputs (mean, variance, alpha)
+absolutely and to lml/gradient relative to their scale; every fixture records cond(K).
+"""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+
+from hbetune_rs_amd import gpr, synth
+from oracle import gpr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+F64_TOL = 1e-8
+F32_TOL = 1e-4
+
+
+def split_theta(theta):
+    return math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_lml_grad_predict_match_golden_f64(path):
+    g = np.load(path)
+    X, y, theta, nu = g["X"], g["y"], g["theta"], float(g["nu"])
+    prob = gpr.Problem(X, y, nu=nu)
+    K = prob.kernel_matrix(theta)
+    np.testing.assert_allclose(K[:4], g["K_rows"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(np.diag(K), g["K_diag"], rtol=1e-12)
+    assert abs(K.sum() - float(g["K_sum"])) <= 1e-10 * abs(float(g["K_sum"]))
+    res = prob.lml_with_gradient(theta)
+    assert res is not None
+    lml, grad = res
+    assert abs(lml - float(g["lml"])) <= F64_TOL * max(1.0, abs(float(g["lml"])))
+    np.testing.assert_allclose(grad, g["grad"], rtol=0, atol=F64_TOL * max(1.0, np.abs(g["grad"]).max()))
+    alpha, kinv, ldiag = prob.results()
+    np.testing.assert_allclose(alpha, g["alpha"], rtol=0, atol=F64_TOL * max(1.0, np.abs(g["alpha"]).max()))
+    # K^-1 against the oracle (LAPACK potri)
+    s2, c, ell = split_theta(theta)
+    ref = O.lml_with_gradient(X, y, s2, c, ell, nu)
+    np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=F64_TOL * np.abs(ref["k_inv"]).max())
+    np.testing.assert_allclose(ldiag, np.diag(ref["chol"]), rtol=1e-10)
+    # model + predict
+    fk = gpr.FittedKernel.extend(X, y, theta, nu=nu)
+    mean, var, n_warn = fk.predict(g["Xs"])
+    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=F64_TOL * max(1.0, np.abs(g["mean"]).max()))
+    np.testing.assert_allclose(var, g["var"], rtol=0, atol=F64_TOL * c)
+    assert n_warn == 0
+    a2, k2 = fk.arrays()
+    np.testing.assert_allclose(k2, ref["k_inv"], rtol=0, atol=F64_TOL * np.abs(ref["k_inv"]).max())
+    assert np.array_equal(k2, k2.T)  # invc_into() hands back the full symmetric matrix
+    assert abs(fk.lml - float(g["lml"])) <= F64_TOL * max(1.0, abs(float(g["lml"])))
+
+
+@pytest.mark.parametrize("cfg,n", [("C2", 1024), ("C1", 64), ("M", 640), ("C3", 384), ("C4", 1100)])
+def test_against_oracle_mid_sizes_f64(cfg, n):
+    w = synth.make_workload(cfg, n=n)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    s2, c, ell = split_theta(theta)
+    ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+    prob = gpr.Problem(X, y, nu=2.5)
+    lml, grad = prob.lml_with_gradient(theta)
+    assert abs(lml - ref["lml"]) <= F64_TOL * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["grad"]).max()))
+    alpha, kinv, _ = prob.results()
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["alpha"]).max()))
+    np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=F64_TOL * np.abs(ref["k_inv"]).max())
+    Xs = synth.candidates(cfg, 200, w["d"])
+    fk = gpr.FittedKernel.extend(X, y, theta)
+    mean, var, _ = fk.predict(Xs)
+    rmean, rvar, _ = O.predict(Xs, X, ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    np.testing.assert_allclose(mean, rmean, rtol=0, atol=F64_TOL * max(1.0, np.abs(rmean).max()))
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=F64_TOL * c)
+
+
+@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5])
+def test_all_matern_orders(nu):
+    w = synth.make_workload("C1")
+    s2, c, ell = split_theta(w["theta"])
+    ref = O.lml_with_gradient(w["X"], w["y"], s2, c, ell, nu)
+    prob = gpr.Problem(w["X"], w["y"], nu=nu)
+    lml, grad = prob.lml_with_gradient(w["theta"])
+    assert abs(lml - ref["lml"]) <= F64_TOL * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["grad"]).max()))
+
+
+def test_f32_path_himmelblau():
+    # C5 (f32, --use-32) at a size the oracle finishes quickly.  Bar: 1e-4 relative to scale against the f64 oracle, or
+    # within 10x of what the reference's own f32 arithmetic (the f32 oracle: LAPACK spotrf/spotri) deviates from f64 --
+    # the reference itself warns its f32 path is unstable (README.md:56-59).
+    w = synth.make_workload("C5", n=512)
+    assert w["X"].dtype == np.float32
+    theta = w["theta"].copy()
+    theta[0] = theta[1] + math.log(0.5)  # keep cond(K) ~ 4e2 so f32 is meaningful
+    s2, c, ell = split_theta(theta)
+    X64, y64 = w["X"].astype(np.float64), w["y"].astype(np.float64)
+    ref = O.lml_with_gradient(X64, y64, s2, c, ell, 2.5)
+    r32 = O.lml_with_gradient(w["X"], w["y"], s2, c, ell, 2.5)
+    prob = gpr.Problem(w["X"], w["y"], nu=2.5)
+    res = prob.lml_with_gradient(theta)
+    assert res is not None
+    lml, grad = res
+    gscale = max(1.0, np.abs(ref["grad"]).max())
+    assert abs(lml - ref["lml"]) <= max(F32_TOL * abs(ref["lml"]), 10 * abs(r32["lml"] - ref["lml"]))
+    assert np.abs(grad - ref["grad"]).max() <= max(F32_TOL * gscale, 10 * np.abs(r32["grad"] - ref["grad"]).max())
+    fk = gpr.FittedKernel.extend(w["X"], w["y"], theta)
+    Xs = synth.candidates("C5", 64, 2).astype(np.float32)
+    mean, var, _ = fk.predict(Xs)
+    assert mean.dtype == np.float32 and var.dtype == np.float32
+    rmean, rvar, _ = O.predict(Xs.astype(np.float64), X64, ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    m32, v32, _ = O.predict(Xs, w["X"], r32["alpha"], r32["k_inv"], c, ell, 2.5)
+    assert np.abs(mean - rmean).max() <= max(F32_TOL * max(1.0, np.abs(rmean).max()), 10 * np.abs(m32 - rmean).max())
+    assert np.abs(var - rvar).max() <= max(F32_TOL * c, 10 * np.abs(v32 - rvar).max())
+
+
+def test_not_positive_definite_contract():
+    # duplicate rows with vanishing noise: reference returns None -> +inf / zero gradient (lml.rs:47-50, fit.rs:105-112)
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5], [0.9, 0.1]])
+    y = np.array([1.0, 2.0, 3.0, 0.5])
+    theta = np.array([math.log(1e-300), 0.0, 0.0, 0.0])
+    prob = gpr.Problem(X, y)
+    assert prob.lml_with_gradient(theta) is None
+    with pytest.raises(gpr.HbegpError) as e:
+        gpr.FittedKernel.extend(X, y, theta)
+    assert e.value.code == gpr.NOT_PD
+    # and the slot recovers for the next theta
+    ok = prob.lml_with_gradient(np.array([math.log(1e-2), 0.0, 0.0, 0.0]))
+    assert ok is not None and np.isfinite(ok[0])
+
+
+def test_bitwise_reproducible():
+    w = synth.make_workload("C2", n=512)
+    prob = gpr.Problem(w["X"], w["y"])
+    a = prob.lml_with_gradient(w["theta"])
+    b = prob.lml_with_gradient(w["theta"])
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+
+
+def test_clamped_theta_and_bounds():
+    # kernel parameters are clamped into their bounds after exp(), the noise is not (fit.rs:94-96)
+    w = synth.make_workload("C1")
+    theta = w["theta"].copy()
+    theta[2] = math.log(1e4)  # beyond the 1e3 upper bound
+    prob = gpr.Problem(w["X"], w["y"])
+    got = prob.lml_with_gradient(theta, w["lo"], w["hi"])
+    theta_c = theta.copy()
+    theta_c[2] = math.log(1e3)
+    want = prob.lml_with_gradient(theta_c)
+    # exp(ln(1e3)) is 1e3 only to an ulp, so compare to rounding rather than bitwise
+    assert abs(got[0] - want[0]) <= 1e-10 * abs(want[0])
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=1e-9)
