@@ -46,6 +46,7 @@ struct GemmOp {
   int klim;       // 0 none | 1: k <= tj | 2: k >= tj | 3: k <= ti | 4: k >= ti   (global tile coordinates)
   int maskA, maskB;  // on storage-diagonal tiles treat elements with col > row as zero (lower-triangular operand)
   int ntiles;     // output tiles of this op (set by the launcher)
+  int reverse;    // walk the tile list backwards (set by the launcher)
   int alpha_neg;  // alpha = -1 instead of +1
   int beta_one;   // beta = 1 instead of 0
 };
@@ -54,6 +55,11 @@ struct GemmLaunch {
   GemmOp op[2];
   int nops;
   const int* info;  // device flag: kernels return immediately when *info != 0
+  // optional static schedule (device memory): workgroup b runs items [sched_off[b], sched_off[b+1]);
+  // item = op << 31 | local tile row << 16 | local tile col, in units of the launch tile size
+  const int* sched_off;
+  const unsigned* sched_items;
+  int sched_nwg;
 };
 
 // ---- launchers (kernels.hip), T in {double, float} ------------------------------------------------------------
@@ -65,7 +71,7 @@ void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P,
 
 // Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag.
 template <typename T>
-void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s);
+void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg = 0);
 
 // alpha = X^T (X y), lml pieces.  X lower-triangular np x np in W2.  part: [np/256][np] scratch.
 template <typename T>

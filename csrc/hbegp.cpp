@@ -13,7 +13,9 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <atomic>
+#include <queue>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -139,6 +141,72 @@ static double op_gflop(const GemmOp& op) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Static schedule of one large GEMM launch: tiles are assigned to a fixed number of resident workgroups by
+// longest-processing-time-first on their contraction depth, so that triangular operands (depth 1..D per tile) do not
+// leave most of the chip waiting for the few deepest tiles.  Built once per problem (shapes repeat every evaluation).
+struct Sched {
+  int* d_off = nullptr;
+  unsigned* d_items = nullptr;
+  int nwg = 0;   // 0: plain launch
+  int tile = 0;
+};
+
+static void tile_krange(const GemmOp& op, int ti, int tj, int* ka, int* kb) {
+  *ka = op.k0; *kb = op.k1;
+  if (op.klim == 1) *kb = std::min(*kb, tj + 1);
+  if (op.klim == 2) *ka = std::max(*ka, tj);
+  if (op.klim == 3) *kb = std::min(*kb, ti + 1);
+  if (op.klim == 4) *ka = std::max(*ka, ti);
+}
+
+// ops in NB units; returns host arrays for `tile`
+static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, std::vector<unsigned>* items, int* nwg_out) {
+  const int f = NB / tile;
+  struct It { double w; unsigned code; };
+  std::vector<It> its;
+  for (int oi = 0; oi < g.nops; ++oi) {
+    GemmOp op = g.op[oi];
+    op.ci0 *= f; op.cj0 *= f; op.mi *= f; op.nj *= f; op.k0 *= f; op.k1 *= f;
+    for (int i = 0; i < op.mi; ++i)
+      for (int j = 0; j < (op.c_lower ? i + 1 : op.nj); ++j) {
+        int ka, kb;
+        tile_krange(op, op.ci0 + i, op.cj0 + j, &ka, &kb);
+        its.push_back({(double)(kb - ka) + 0.75, ((unsigned)oi << 31) | ((unsigned)i << 16) | (unsigned)j});
+      }
+  }
+  const int ntiles = (int)its.size();
+  const int occmax = tile == 128 ? 2 : 4;
+  // Above ~2 tiles per resident slot the hardware dispatcher (tiles are listed deepest-first) balances better than a
+  // static list (measured: LAUUM at n=4096, 2080 tiles: 50 vs 47 TFLOP/s); below it the static list wins (TRSM 29 -> 44).
+  int nwg = 0;
+  if (ntiles < 2 * 256 * occmax)
+    for (int cand = 256 * occmax; cand >= 256; cand /= 2)
+      if (ntiles >= 2 * cand) { nwg = cand; break; }
+  static const int sched_on = env_int("HBEGP_SCHED", 1);
+  if (!sched_on || nwg == 0) return false;
+  std::stable_sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.w > b.w; });
+  typedef std::pair<double, int> Load;  // (load, wg)
+  std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
+  for (int w = 0; w < nwg; ++w) pq.push({0.0, w});
+  std::vector<std::vector<unsigned>> per(nwg);
+  for (const It& it : its) {
+    Load l = pq.top();
+    pq.pop();
+    per[l.second].push_back(it.code);
+    pq.push({l.first + it.w, l.second});
+  }
+  off->assign(nwg + 1, 0);
+  items->clear();
+  for (int w = 0; w < nwg; ++w) {
+    (*off)[w] = (int)items->size();
+    items->insert(items->end(), per[w].begin(), per[w].end());
+  }
+  (*off)[nwg] = (int)items->size();
+  *nwg_out = nwg;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 struct Slot {
   int dev = 0;
@@ -157,6 +225,7 @@ struct Slot {
   int best_run = 0, best_eval = 0;
   std::vector<double> best_theta;
   int last_target = 0;  // buffer written by the most recent evaluation
+  int gemm_ord = 0;     // ordinal of the next GEMM launch inside the current evaluation (indexes the static schedules)
 };
 
 struct ProblemBase {
@@ -175,6 +244,8 @@ template <typename T>
 struct Problem : ProblemBase {
   std::vector<T*> Xd, yd;                 // per device
   std::vector<std::vector<Slot<T>>> slots;  // [device][slot]
+  std::vector<std::vector<Sched>> scheds;   // [device][gemm launch ordinal]
+  bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
 
   Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_) {
     ctx = c; n = n_; d = d_; np = round_up(n_, NB); n_slots = n_slots_;
@@ -219,6 +290,14 @@ struct Problem : ProblemBase {
       }
       HIPCHECK(hipDeviceSynchronize());
     }
+    // build the static GEMM schedules (per device; shared by its slots) by walking one evaluation without launching
+    scheds.resize(c->devs.size());
+    dry_ = true;
+    for (size_t di = 0; di < c->devs.size(); ++di) {
+      HIPCHECK(hipSetDevice(c->devs[di]));
+      enqueue_eval(slots[di][0], di, 0, true, nullptr);
+    }
+    dry_ = false;
   }
   ~Problem() override {
     for (size_t di = 0; di < slots.size(); ++di) {
@@ -236,35 +315,60 @@ struct Problem : ProblemBase {
         if (s.stream) (void)hipStreamDestroy(s.stream);
       }
       (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
+      if (di < scheds.size())
+        for (auto& sc : scheds[di]) { (void)hipFree(sc.d_off); (void)hipFree(sc.d_items); }
     }
   }
 
-  void gemm(Slot<T>& s, GemmLaunch& g, PhaseTimer* tm, int kind) {
+  void gemm(Slot<T>& s, size_t di, GemmLaunch& g, PhaseTimer* tm, int kind) {
     g.info = &s.dOut->info;
-    int tiles = 0;
-    double gf = 0;
-    for (int i = 0; i < g.nops; ++i) {
-      const GemmOp& op = g.op[i];
-      tiles += op.c_lower ? op.mi * (op.mi + 1) / 2 : op.mi * op.nj;
-      if (tm) gf += op_gflop(op);
+    const int ord = s.gemm_ord++;
+    if (dry_) {
+      int tiles = 0;
+      for (int i = 0; i < g.nops; ++i) {
+        const GemmOp& op = g.op[i];
+        tiles += op.c_lower ? op.mi * (op.mi + 1) / 2 : op.mi * op.nj;
+      }
+      Sched sc;
+      sc.tile = pick_tile(tiles);
+      std::vector<int> off;
+      std::vector<unsigned> items;
+      int nwg = 0;
+      if (build_sched(g, sc.tile, &off, &items, &nwg)) {
+        sc.nwg = nwg;
+        HIPCHECK(hipMalloc(&sc.d_off, sizeof(int) * off.size()));
+        HIPCHECK(hipMalloc(&sc.d_items, sizeof(unsigned) * items.size()));
+        HIPCHECK(hipMemcpy(sc.d_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(sc.d_items, items.data(), sizeof(unsigned) * items.size(), hipMemcpyHostToDevice));
+      }
+      if ((int)scheds[di].size() <= ord) scheds[di].resize(ord + 1);
+      scheds[di][ord] = sc;
+      return;
     }
-    const int tile = pick_tile(tiles);
-    if (tm) tm->begin(kind, tile, gf);
-    launch_gemm<T>(g, tile, s.stream);
+    const Sched& sc = scheds[di][ord];
+    g.sched_off = sc.nwg ? sc.d_off : nullptr;
+    g.sched_items = sc.nwg ? sc.d_items : nullptr;
+    g.sched_nwg = sc.nwg;
+    double gf = 0;
+    if (tm)
+      for (int i = 0; i < g.nops; ++i) gf += op_gflop(g.op[i]);
+    if (tm) tm->begin(kind, sc.tile, gf);
+    launch_gemm<T>(g, sc.tile, s.stream);
     if (tm) tm->end();
   }
 
   // Cholesky + inverse of the factor on the diagonal block range [lo, hi) (units of 128): on return W2 holds
   // X = L^-1 on that range (lower), ldiag the diagonal of L.
-  void chol_inv(Slot<T>& s, int lo, int hi, PhaseTimer* tm) {
+  void chol_inv(Slot<T>& s, size_t di, int lo, int hi, PhaseTimer* tm) {
     if (hi - lo == 1) {
+      if (dry_) return;
       if (tm) tm->begin(PhaseTimer::LEAF);
       launch_leaf<T>(s.W1, s.W2, np, lo, s.ldiag, &s.dOut->info, s.stream);
       if (tm) tm->end();
       return;
     }
     const int mid = lo + (hi - lo) / 2;
-    chol_inv(s, lo, mid, tm);
+    chol_inv(s, di, lo, mid, tm);
     GemmOp base{};
     base.lda = base.ldb = base.ldc = np;
     {
@@ -277,7 +381,7 @@ struct Problem : ProblemBase {
       op.a_kmajor = 0; op.b_kmajor = 0;
       op.ci0 = mid; op.mi = hi - mid; op.cj0 = lo; op.nj = mid - lo;
       op.k0 = lo; op.k1 = mid; op.klim = 1; op.maskB = 1;
-      gemm(s, g, tm, PhaseTimer::GEMM);
+      gemm(s, di, g, tm, PhaseTimer::GEMM);
     }
     {
       // A22 -= T T^T (lower)   and   U = T * X11 -> W1[2,1]   (independent: one launch)
@@ -294,9 +398,9 @@ struct Problem : ProblemBase {
       u.a_kmajor = 0; u.b_kmajor = 1;
       u.ci0 = mid; u.mi = hi - mid; u.cj0 = lo; u.nj = mid - lo;
       u.k0 = lo; u.k1 = mid; u.klim = 2; u.maskB = 1;
-      gemm(s, g, tm, PhaseTimer::GEMM);
+      gemm(s, di, g, tm, PhaseTimer::GEMM);
     }
-    chol_inv(s, mid, hi, tm);
+    chol_inv(s, di, mid, hi, tm);
     {
       // X21 = -X22 * U -> W2[2,1]
       GemmLaunch g{};
@@ -307,22 +411,27 @@ struct Problem : ProblemBase {
       op.a_kmajor = 0; op.b_kmajor = 1;
       op.ci0 = mid; op.mi = hi - mid; op.cj0 = lo; op.nj = mid - lo;
       op.k0 = mid; op.k1 = hi; op.klim = 3; op.maskA = 1; op.alpha_neg = 1;
-      gemm(s, g, tm, PhaseTimer::GEMM);
+      gemm(s, di, g, tm, PhaseTimer::GEMM);
     }
   }
 
   void enqueue_eval(Slot<T>& s, size_t di, int target, bool want_grad, PhaseTimer* tm) {
     const int nb = np / NB;
-    HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
-    HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+    s.gemm_ord = 0;
     const int* info = &s.dOut->info;
-    if (tm) tm->begin(PhaseTimer::KMAT);
-    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
-    if (tm) tm->end();
-    chol_inv(s, 0, nb, tm);
-    if (tm) tm->begin(PhaseTimer::ALPHA);
-    launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);
-    if (tm) tm->end();
+    if (!dry_) {
+      HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
+      HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+      if (tm) tm->begin(PhaseTimer::KMAT);
+      launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+      if (tm) tm->end();
+    }
+    chol_inv(s, di, 0, nb, tm);
+    if (!dry_) {
+      if (tm) tm->begin(PhaseTimer::ALPHA);
+      launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);
+      if (tm) tm->end();
+    }
     {
       // K^-1 = X^T X (lower)  [LAUUM]
       GemmLaunch g{};
@@ -333,8 +442,9 @@ struct Problem : ProblemBase {
       op.a_kmajor = 1; op.b_kmajor = 1;
       op.ci0 = 0; op.cj0 = 0; op.mi = nb; op.nj = nb; op.c_lower = 1;
       op.k0 = 0; op.k1 = nb; op.klim = 4; op.maskA = 1; op.maskB = 1;
-      gemm(s, g, tm, PhaseTimer::LAUUM);
+      gemm(s, di, g, tm, PhaseTimer::LAUUM);
     }
+    if (dry_) return;
     if (want_grad) {
       if (tm) tm->begin(PhaseTimer::GRAD);
       launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream);
@@ -429,6 +539,10 @@ struct Problem : ProblemBase {
           float dt = 0;
           HIPCHECK(hipEventElapsedTime(&dt, rec.a, rec.b));
           const double v = dt / treps;
+          static const bool dump = env_int("HBEGP_TRACE_LAUNCHES", 0) != 0;
+          if (dump && r == treps - 1)
+            fprintf(stderr, "launch kind=%d tile=%d gflop=%.4f ms=%.4f tflops=%.2f\n", rec.kind, rec.tile, rec.gflop, dt,
+                    dt > 0 ? rec.gflop / dt : 0.0);
           if (rec.kind == PhaseTimer::KMAT) phase_ms[0] += v;
           if (rec.kind == PhaseTimer::GEMM) { phase_ms[1] += v; phase_ms[7] += 1.0 / treps; }
           if (rec.kind == PhaseTimer::LEAF) { phase_ms[2] += v; phase_ms[15] += 1.0 / treps; }

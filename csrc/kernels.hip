@@ -71,12 +71,14 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 template <typename T, int TILE>
 struct GemmGeom {
   using C = Cfg<T>;
-  static constexpr int SK = C::BK + 2;        // LDS row stride, operand stored [outer][k]
+  // contraction depth per LDS stage: 128 bytes of k for the big tiles, 512 bytes for the 32-tiles (small, latency-bound
+  // launches: fewer, fatter stages)
+  static constexpr int BKE = (TILE == 32 ? 4 : 1) * C::BK;
+  static constexpr int SK = BKE + 2;          // LDS row stride, operand stored [outer][k]
   static constexpr int SM = TILE + 16;        // LDS row stride, operand stored [k][outer]
-  static constexpr int LDSE = (TILE * SK > C::BK * SM) ? TILE * SK : C::BK * SM;  // elements per operand buffer
-  static constexpr int NCH = TILE / 32;       // 16-byte chunks per thread per operand per stage
+  static constexpr int LDSE = (TILE * SK > BKE * SM) ? TILE * SK : BKE * SM;  // elements per operand buffer
+  static constexpr int NCH = TILE * BKE / C::VEC / 256;  // 16-byte chunks per thread per operand per stage
   static constexpr int TM = TILE / 32;        // 16x16 MFMA blocks per wave per dimension
-  static constexpr int SPT = TILE / C::BK;    // stages per contraction tile
 };
 
 __device__ __forceinline__ int tri_row(int idx) {
@@ -93,26 +95,41 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   using G = GemmGeom<T, TILE>;
   using vec_t = typename C::vec_t;
   using acc_t = typename C::acc_t;
-  constexpr int VEC = C::VEC, BK = C::BK, SK = G::SK, SM = G::SM, NCH = G::NCH, TM = G::TM, SPT = G::SPT;
+  constexpr int VEC = C::VEC, BK = G::BKE, SK = G::SK, SM = G::SM, NCH = G::NCH, TM = G::TM;
 
   if (*g.info != 0) return;
 
-  int bid = blockIdx.x;
-  int oi = 0;
-  if (g.nops > 1 && bid >= g.op[0].ntiles) {
-    oi = 1;
-    bid -= g.op[0].ntiles;
+  // Work list of this workgroup: either one tile decoded from blockIdx (plain launches) or a host-built static
+  // schedule (longest-processing-time assignment of tiles to a fixed number of resident workgroups, see hbegp.cpp).
+  int it = 0, it_end = 1;
+  if (g.sched_off) {
+    it = g.sched_off[blockIdx.x];
+    it_end = g.sched_off[blockIdx.x + 1];
+  }
+  for (; it < it_end; ++it) {
+  int oi = 0, li, lj;
+  if (g.sched_off) {
+    const unsigned item = g.sched_items[it];
+    oi = item >> 31;
+    li = (item >> 16) & 0x7fff;
+    lj = item & 0xffff;
+  } else {
+    int bid = blockIdx.x;
+    if (g.nops > 1 && bid >= g.op[0].ntiles) {
+      oi = 1;
+      bid -= g.op[0].ntiles;
+    }
+    const GemmOp& o = g.op[oi];
+    if (o.reverse) bid = o.ntiles - 1 - bid;  // heaviest tiles first
+    if (o.c_lower) {
+      li = tri_row(bid);
+      lj = bid - li * (li + 1) / 2;
+    } else {
+      li = bid / o.nj;
+      lj = bid - li * o.nj;
+    }
   }
   const GemmOp& op = g.op[oi];
-
-  int li, lj;
-  if (op.c_lower) {
-    li = tri_row(bid);
-    lj = bid - li * (li + 1) / 2;
-  } else {
-    li = bid / op.nj;
-    lj = bid - li * op.nj;
-  }
   const int ti = op.ci0 + li, tj = op.cj0 + lj;
 
   int ka = op.k0, kb = op.k1;
@@ -123,7 +140,10 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
     case 4: ka = max(ka, ti); break;
     default: break;
   }
-  const int nstages = (kb - ka) * SPT;
+  // contraction range in elements, rounded outward to whole stages.  The extension stays inside the same 128-block:
+  // there a triangular operand is zero by the element-wise mask below and the other operand is finite.
+  const int kbeg = (ka * TILE) / BK * BK, kend = (kb * TILE + BK - 1) / BK * BK;
+  const int nstages = (kend - kbeg) / BK;
 
   extern __shared__ __align__(16) char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);  // [A buf0 | A buf1 | B buf0 | B buf1], LDSE elements each
@@ -136,19 +156,20 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
 
   // Per-thread chunk 0 of a stage slab: storage (row, col) relative to the slab origin; chunk q = chunk 0 + q row passes.
   constexpr int CPR = TILE / VEC;        // chunks per slab row, operand stored [k][outer]
-  constexpr int RPP_K = 32;              // slab rows covered per pass, operand stored [outer][k] (8 chunks per row)
+  constexpr int CPK = BK / VEC;          // chunks per slab row, operand stored [outer][k]
+  constexpr int RPP_K = 256 / CPK;       // slab rows covered per pass, operand stored [outer][k]
   constexpr int RPP_M = 256 / CPR;       // slab rows covered per pass, operand stored [k][outer]
-  const int a_r0 = akm ? t / CPR : t >> 3, a_c0 = akm ? (t % CPR) * VEC : (t & 7) * VEC;
-  const int b_r0 = bkm ? t / CPR : t >> 3, b_c0 = bkm ? (t % CPR) * VEC : (t & 7) * VEC;
+  const int a_r0 = akm ? t / CPR : t / CPK, a_c0 = akm ? (t % CPR) * VEC : (t % CPK) * VEC;
+  const int b_r0 = bkm ? t / CPR : t / CPK, b_c0 = bkm ? (t % CPR) * VEC : (t % CPK) * VEC;
   const int a_rpp = akm ? RPP_M : RPP_K, b_rpp = bkm ? RPP_M : RPP_K;
   const int a_lds0 = a_r0 * (akm ? SM : SK) + a_c0, a_ldsq = a_rpp * (akm ? SM : SK);
   const int b_lds0 = 2 * G::LDSE + b_r0 * (bkm ? SM : SK) + b_c0, b_ldsq = b_rpp * (bkm ? SM : SK);
 
   // global pointers of chunk 0 at stage 0; they advance by a uniform stride per stage
   const T* pA = static_cast<const T*>(op.A) +
-                (akm ? (size_t)(ka * TILE + a_r0) * lda + ti * TILE + a_c0 : (size_t)(ti * TILE + a_r0) * lda + ka * TILE + a_c0);
+                (akm ? (size_t)(kbeg + a_r0) * lda + ti * TILE + a_c0 : (size_t)(ti * TILE + a_r0) * lda + kbeg + a_c0);
   const T* pB = static_cast<const T*>(op.B) +
-                (bkm ? (size_t)(ka * TILE + b_r0) * ldb + tj * TILE + b_c0 : (size_t)(tj * TILE + b_r0) * ldb + ka * TILE + b_c0);
+                (bkm ? (size_t)(kbeg + b_r0) * ldb + tj * TILE + b_c0 : (size_t)(tj * TILE + b_r0) * ldb + kbeg + b_c0);
   const size_t a_step = akm ? (size_t)BK * lda : (size_t)BK, b_step = bkm ? (size_t)BK * ldb : (size_t)BK;
   const size_t a_qs = (size_t)a_rpp * lda, b_qs = (size_t)b_rpp * ldb;
 
@@ -161,26 +182,25 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
     for (int q = 0; q < NCH; ++q) rb[q] = *reinterpret_cast<const vec_t*>(pB + q * b_qs);
     pA += a_step;
     pB += b_step;
-    const int tk = ka + s / SPT;
-    if ((op.maskA && tk == ti) || (op.maskB && tk == tj)) {  // storage-diagonal tile of a triangular operand (uniform branch)
-      const int kk = tk * TILE + (s % SPT) * BK;
-      if (op.maskA && tk == ti) {
+    // lower-triangular operands: zero the storage elements with col > row (uniform branches; only slabs that reach
+    // above the diagonal pay for it)
+    const int kk = kbeg + s * BK;
+    if (op.maskA && (akm ? ti * TILE + TILE - 1 > kk : kk + BK - 1 > ti * TILE)) {
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) {
-          const int gr = (akm ? kk : ti * TILE) + a_r0 + q * a_rpp, gc = (akm ? ti * TILE : kk) + a_c0;
+      for (int q = 0; q < NCH; ++q) {
+        const int gr = (akm ? kk : ti * TILE) + a_r0 + q * a_rpp, gc = (akm ? ti * TILE : kk) + a_c0;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            if (gc + e > gr) ra[q][e] = 0;
-        }
+        for (int e = 0; e < VEC; ++e)
+          if (gc + e > gr) ra[q][e] = 0;
       }
-      if (op.maskB && tk == tj) {
+    }
+    if (op.maskB && (bkm ? tj * TILE + TILE - 1 > kk : kk + BK - 1 > tj * TILE)) {
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) {
-          const int gr = (bkm ? kk : tj * TILE) + b_r0 + q * b_rpp, gc = (bkm ? tj * TILE : kk) + b_c0;
+      for (int q = 0; q < NCH; ++q) {
+        const int gr = (bkm ? kk : tj * TILE) + b_r0 + q * b_rpp, gc = (bkm ? tj * TILE : kk) + b_c0;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            if (gc + e > gr) rb[q][e] = 0;
-        }
+        for (int e = 0; e < VEC; ++e)
+          if (gc + e > gr) rb[q][e] = 0;
       }
     }
   };
@@ -246,6 +266,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
         if (op.beta_one) v += *p;
         *p = v;
       }
+  }  // work list
 }
 
 template <typename T, int TILE>
@@ -256,8 +277,11 @@ static void launch_gemm_t(const GemmLaunch& gl, hipStream_t s) {
   for (int i = 0; i < g.nops; ++i) {
     GemmOp& op = g.op[i];
     op.ntiles = op.c_lower ? op.mi * (op.mi + 1) / 2 : op.mi * op.nj;
+    // heaviest tiles first: contraction depth grows with tj (klim 1) or ti (klim 3) -> walk those tile lists backwards
+    op.reverse = (op.klim == 1 || op.klim == 3) ? 1 : 0;
     total += op.ntiles;
   }
+  if (g.sched_off) total = g.sched_nwg;
   if (total <= 0) return;
   const size_t lds = (size_t)4 * G::LDSE * sizeof(T);
   hipLaunchKernelGGL((gemm_kernel<T, TILE>), dim3(total), dim3(256), lds, s, g);
@@ -292,7 +316,7 @@ struct LeafGeom {
 
 template <typename T>
 __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __restrict__ W2, int ld, int blk,
-                                                   T* __restrict__ ldiag, int* info) {
+                                                   T* __restrict__ ldiag, int* info, int dbg) {
   using C = Cfg<T>;
   using L = LeafGeom<T>;
   using acc_t = typename C::acc_t;
@@ -311,64 +335,157 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
   T* Ablk = W1 + g0;
   T* Xblk = W2 + g0;
 
-  // load the block (coalesced 16-byte chunks)
-  for (int c = t; c < 128 * (128 / VEC); c += 256) {
-    const int r = c / (128 / VEC), cc = (c % (128 / VEC)) * VEC;
-    vec_t v = *reinterpret_cast<const vec_t*>(Ablk + (size_t)r * ld + cc);
+  // load the block: all 16-byte chunks of a batch are issued before the first LDS store, so the loads overlap
+  {
+    constexpr int CPRW = 128 / VEC;             // chunks per row
+    constexpr int NCHUNK = 128 * CPRW / 256;     // chunks per thread
+    constexpr int BATCH = 16;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = v[e];
+    for (int b0 = 0; b0 < NCHUNK; b0 += BATCH) {
+      vec_t buf[BATCH];
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int c = t + 256 * (b0 + q);
+        const int r = c / CPRW, cc = (c % CPRW) * VEC;
+        buf[q] = *reinterpret_cast<const vec_t*>(Ablk + (size_t)r * ld + cc);
+      }
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int c = t + 256 * (b0 + q);
+        const int r = c / CPRW, cc = (c % CPRW) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = buf[q][e];
+      }
+    }
   }
   __syncthreads();
 
-  // ---------------- phase 1: blocked right-looking Cholesky, 16-wide panels ----------------
+  // ---------------- phase 1: blocked right-looking Cholesky, 16-wide panels, look-ahead of one panel ----------------
+  // Per panel p:  (A) wave 0 factors the 16x16 diagonal block (registers + lane broadcasts) while waves 1-3 finish the
+  //               trailing update of panel p-1 on block columns >= p+1;
+  //               (B) all waves: L[i,p] = A[i,p] Y_pp^T;  (C) all waves: update of block column p+1 only.
+  auto update_block = [&](int i, int j, int pp) {  // A[i,j] -= L[i,pp] L[j,pp]^T
+    acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const T af = As[(i * 16 + m16) * S + pp * 16 + k4 * 4 + q4];
+      const T bf = As[(j * 16 + m16) * S + pp * 16 + k4 * 4 + q4];
+      acc = C::mfma(af, bf, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T* pc = &As[(i * 16 + C::crow(lane, r)) * S + j * 16 + m16];
+      *pc = *pc - acc[r];
+    }
+  };
+
+  // X = L^-1 block by block: X[i,i] = Y_ii ; X[i,j] = -Y_ii * sum_{k=j}^{i-1} L[i,k] X[k,j]  (i > j).
+  // X[k,j] (k > j) is kept transposed in the upper part of As; block row i only needs rows < i, L[i,:] and Y_ii.
+  T* sc = Sc + wave * YB;
+  auto xinv_block = [&](int i, int j) {
+    acc_t acc = {0, 0, 0, 0};
+    for (int k = j; k < i; ++k) {
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const T af = As[(i * 16 + m16) * S + k * 16 + k4 * 4 + q4];
+        T bf;
+        if (k == j) bf = Ys[j * YB + (k4 * 4 + q4) * YS + m16];
+        else bf = As[(j * 16 + m16) * S + k * 16 + k4 * 4 + q4];
+        acc = C::mfma(af, bf, acc);
+      }
+    }
+    // stage the sum through wave-private LDS to re-read it as a B operand
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[C::crow(lane, r) * YS + m16] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    acc_t res = {0, 0, 0, 0};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const T af = Ys[i * YB + m16 * YS + k4 * 4 + q4];
+      const T bf = sc[(k4 * 4 + q4) * YS + m16];
+      res = C::mfma(af, bf, res);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = C::crow(lane, r);
+      const T v = -res[r];
+      As[(j * 16 + m16) * S + i * 16 + row] = v;             // transposed copy for later products
+      Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16] = v;  // X[i,j]
+    }
+  };
+
   for (int p = 0; p < 8; ++p) {
-    if (wave == 0) {
+    if (wave == 0 && !(dbg & 1)) {
       // 16x16 diagonal block: lane r (and its 3 replicas) owns row r of [A | I]; forward elimination gives L and L^-1.
+      // No per-lane predicates on the A side: entries above the diagonal only ever feed themselves.
       const int r = m16;
-      T a[16], yv[16];
+      T a[16], tv[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         a[j] = As[(p * 16 + r) * S + p * 16 + j];
-        yv[j] = (j == r) ? T(1) : T(0);
+        tv[j] = (j == r) ? T(1) : T(0);
       }
       bool bad = false;
+      T rinv_own = T(0);
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const T piv = readlane(a[k], k);
-        if (!(piv > T(0))) bad = true;
-        const T rinv = T(1) / sqrt(piv);
-        const T lk = a[k] * rinv;  // l_{r,k}
+        bad = bad || !(piv > T(0));
+        // 1/sqrt(piv): hardware estimate + two Newton steps (full double precision)
+        T rinv = __builtin_amdgcn_rsq(piv);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const T gg = piv * rinv, hh = T(0.5) * rinv;
+          const T ee = __builtin_fma(-hh, gg, T(0.5));
+          rinv = __builtin_fma(rinv, ee, rinv);
+        }
+        const T lk = a[k] * rinv;  // l_{r,k} for r >= k (for r == k: sqrt(piv))
         a[k] = lk;
+        rinv_own = (r == k) ? rinv : rinv_own;
 #pragma unroll
-        for (int j = k + 1; j < 16; ++j) {
-          const T ljk = readlane(lk, j);
-          if (r > k) a[j] -= lk * ljk;
-        }
+        for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, readlane(lk, j), a[j]);
+        // inverse side on the un-normalised rows t: rows r > k get t_r -= l_rk * (t_k / l_kk); rows <= k are final
+        const T lkm = (r > k) ? lk * rinv : T(0);
 #pragma unroll
-        for (int j = 0; j <= k; ++j) {
-          const T ykj = readlane(yv[j], k) * rinv;
-          if (r > k) yv[j] -= lk * ykj;
-          else if (r == k) yv[j] = ykj;
-        }
+        for (int j = 0; j <= k; ++j) tv[j] = __builtin_fma(-lkm, readlane(tv[j], k), tv[j]);
       }
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           if (j <= r) As[(p * 16 + r) * S + p * 16 + j] = a[j];
-          Ys[p * YB + r * YS + j] = (j <= r) ? yv[j] : T(0);
+          Ys[p * YB + r * YS + j] = (j <= r) ? tv[j] * rinv_own : T(0);
         }
         T dv = T(0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (j == r) dv = a[j];
+        for (int j = 0; j < 16; ++j) dv = (j == r) ? a[j] : dv;
         ldiag[blk * NB + p * 16 + r] = dv;
       }
       if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
+    } else if (p > 0 && wave > 0) {
+      // waves 1-3 meanwhile: block row p-1 of the inverse, then the rest of the trailing update of panel p-1
+      // (blocks (i,j), p+1 <= j <= i <= 7); one combined work list dealt round-robin
+      const int nx = (dbg & 2) ? 0 : p - 1;
+      const int tcount = 7 - p;
+      const int nupd = (dbg & 4) ? 0 : tcount * (tcount + 1) / 2;
+      for (int idx = wave - 1; idx < nx + nupd; idx += 3) {
+        if (idx < nx) {
+          xinv_block(p - 1, idx);
+        } else {
+          const int u = idx - nx;
+          const int li = tri_row(u), lj = u - li * (li + 1) / 2;
+          update_block(p + 1 + li, p + 1 + lj, p - 1);
+        }
+      }
     }
     __syncthreads();
+    if (p == 7) break;
 
-    // panel: L[i,p] = A[i,p] * Y_pp^T, i > p
-    for (int i = p + 1 + wave; i < 8; i += 4) {
+    // (B) panel: L[i,p] = A[i,p] * Y_pp^T, i > p
+    for (int i = p + 1 + wave; i < 8 && !(dbg & 4); i += 4) {
       acc_t acc = {0, 0, 0, 0};
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
@@ -381,72 +498,15 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
     }
     __syncthreads();
 
-    // trailing update inside the block: A[i,j] -= L[i,p] L[j,p]^T, p < j <= i
-    {
-      const int tcount = 7 - p;
-      const int nblk = tcount * (tcount + 1) / 2;
-      for (int idx = wave; idx < nblk; idx += 4) {
-        const int li = tri_row(idx), lj = idx - li * (li + 1) / 2;
-        const int i = p + 1 + li, j = p + 1 + lj;
-        acc_t acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const T af = As[(i * 16 + m16) * S + p * 16 + k4 * 4 + q4];
-          const T bf = As[(j * 16 + m16) * S + p * 16 + k4 * 4 + q4];
-          acc = C::mfma(af, bf, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          T* pc = &As[(i * 16 + C::crow(lane, r)) * S + j * 16 + m16];
-          *pc = *pc - acc[r];
-        }
-      }
-    }
+    // (C) block column p+1 only: A[i,p+1] -= L[i,p] L[p+1,p]^T, i >= p+1
+    for (int i = p + 1 + wave; i < 8 && !(dbg & 4); i += 4) update_block(i, p + 1, p);
     __syncthreads();
   }
 
-  // ---------------- phase 2: X = L^-1 by block sub-diagonals ----------------
-  // X[i,i] = Y_ii ; X[i,j] = -Y_ii * sum_{k=j}^{i-1} L[i,k] X[k,j].  X[k,j] (k>j) is kept transposed in the upper part of As.
-  T* sc = Sc + wave * YB;
-  for (int sd = 1; sd < 8; ++sd) {
-    for (int j = wave; j + sd < 8; j += 4) {
-      const int i = j + sd;
-      acc_t acc = {0, 0, 0, 0};
-      for (int k = j; k < i; ++k) {
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const T af = As[(i * 16 + m16) * S + k * 16 + k4 * 4 + q4];
-          T bf;
-          if (k == j) bf = Ys[j * YB + (k4 * 4 + q4) * YS + m16];
-          else bf = As[(j * 16 + m16) * S + k * 16 + k4 * 4 + q4];
-          acc = C::mfma(af, bf, acc);
-        }
-      }
-      // stage S through wave-private LDS to re-read it as a B operand
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sc[C::crow(lane, r) * YS + m16] = acc[r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      acc_t res = {0, 0, 0, 0};
-#pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const T af = Ys[i * YB + m16 * YS + k4 * 4 + q4];
-        const T bf = sc[(k4 * 4 + q4) * YS + m16];
-        res = C::mfma(af, bf, res);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = C::crow(lane, r);
-        const T v = -res[r];
-        As[(j * 16 + m16) * S + i * 16 + row] = v;                       // transposed copy for later products
-        Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16] = v;            // X[i,j]
-      }
-    }
-    __syncthreads();
-  }
+  // ---------------- tail of the inverse: block row 7 (rows 0..6 were produced inside the panel loop) ----------------
+  if (!(dbg & 2))
+    for (int j = wave; j < 7; j += 4) xinv_block(7, j);
+  __syncthreads();
   // diagonal sub-blocks of X
   for (int c = t; c < 8 * 256; c += 256) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
@@ -455,11 +515,11 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
 }
 
 template <typename T>
-void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s) {
-  hipLaunchKernelGGL((leaf_kernel<T>), dim3(1), dim3(256), LeafGeom<T>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info);
+void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg) {
+  hipLaunchKernelGGL((leaf_kernel<T>), dim3(1), dim3(256), LeafGeom<T>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg);
 }
-template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t);
-template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t);
+template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t, int);
+template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t, int);
 
 // =================================================================================================================
 // Kernel-matrix assembly

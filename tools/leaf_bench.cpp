@@ -1,0 +1,37 @@
+// Times the diagonal-block (leaf) kernel with parts switched off (diagnostic build flags), to see where its time goes.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Icsrc tools/leaf_bench.cpp build/kernels.o -o tools/leaf_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "engine.hpp"
+namespace hbegp { void init_kernels(); }
+using namespace hbegp;
+int main() {
+  const int nb = 32, np = nb * 128;
+  std::vector<double> h((size_t)np * np, 0.0);
+  for (int b = 0; b < nb; ++b)
+    for (int i = 0; i < 128; ++i)
+      for (int j = 0; j < 128; ++j) {
+        size_t r = b * 128 + i, c = b * 128 + j;
+        h[r * np + c] = (i == j ? 4.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+      }
+  double *W1, *W2, *ld; int* info;
+  hipMalloc(&W1, sizeof(double) * h.size()); hipMalloc(&W2, sizeof(double) * h.size()); hipMalloc(&ld, sizeof(double) * np);
+  hipMalloc(&info, 4); hipMemset(info, 0, 4); hipMemset(W2, 0, sizeof(double) * h.size());
+  init_kernels();
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int dbg : {0, 1, 2, 4, 3, 5, 6, 7}) {
+    hipMemcpy(W1, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    launch_leaf<double>(W1, W2, np, 0, ld, info, 0, dbg);
+    hipMemcpy(W1, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int b = 0; b < nb; ++b) launch_leaf<double>(W1, W2, np, b, ld, info, 0, dbg);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    int hinfo; hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost); hipMemset(info, 0, 4);
+    printf("dbg=%d (skip diag=%d phase2=%d mfma-phase1=%d): %.2f us per leaf (info=%d)\n", dbg, dbg & 1, (dbg >> 1) & 1, (dbg >> 2) & 1,
+           ms * 1000 / nb, hinfo);
+  }
+  return 0;
+}
