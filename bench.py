@@ -69,21 +69,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np  # noqa: F401
+    import torch  # noqa: F401  (loaded before libhbegp.so so the process holds one HIP runtime)
 
-    import numpy as np
-    import torch
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
+    from hbetune_rs_amd import dist as D
     from hbetune_rs_amd import gpr, synth
+
+    rank, local_rank, world = D.rank_info()
+    if args.gpus != world:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+    dist = D.init("nccl") if world > 1 else None
 
     w = synth.make_workload("M", n=args.n)
     X, y, theta = w["X"], w["y"], w["theta"]
@@ -100,24 +95,14 @@ def main():
         fk.release()
         return mean, var
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    D.barrier(dist)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    D.barrier(dist)
+    elapsed = D.max_over_ranks(dist, time.perf_counter() - t0)
 
     out = None
     if rank == 0:
@@ -176,7 +161,7 @@ def main():
             out["speedup_vs_cpu_port"] = value / cb["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        D.barrier(dist)
         dist.destroy_process_group()
     ctx.close()
 

@@ -113,8 +113,8 @@ struct PhaseTimer {
 static int pick_tile(int tiles128) {
   static const int forced = env_int("HBEGP_TILE", 0);
   if (forced == 32 || forced == 64 || forced == 128) return forced;
-  if (tiles128 >= env_int("HBEGP_T128_MIN", 192)) return 128;
-  if (tiles128 >= env_int("HBEGP_T64_MIN", 24)) return 64;
+  if (tiles128 >= env_int("HBEGP_T128_MIN", 2048)) return 128;  // n >= 16384: below that 64-tiles balance better (measured)
+  if (tiles128 >= env_int("HBEGP_T64_MIN", 100)) return 64;
   return 32;
 }
 
@@ -278,7 +278,7 @@ struct Problem : ProblemBase {
         HIPCHECK(hipMemset(s.W1, 0, sizeof(T) * nn));
         HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));
-        HIPCHECK(hipMalloc(&s.part_t, sizeof(double) * (size_t)((np + 255) / 256) * np));
+        HIPCHECK(hipMalloc(&s.part_t, sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64)));
         HIPCHECK(hipMalloc(&s.part_g, sizeof(double) * gradtrace_part_elems(np, d)));
         HIPCHECK(hipMalloc(&s.dP, sizeof(EvalParams)));
         HIPCHECK(hipMalloc(&s.dOut, sizeof(EvalOut)));

@@ -97,7 +97,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   using acc_t = typename C::acc_t;
   constexpr int VEC = C::VEC, BK = G::BKE, SK = G::SK, SM = G::SM, NCH = G::NCH, TM = G::TM;
 
-  if (*g.info != 0) return;
+  // The not-positive-definite flag is only needed before anything is written: load it now, test it in the epilogue, so
+  // its latency overlaps the operand loads (work on garbage is harmless, stores are not).
+  const int bad = *g.info;
 
   // Work list of this workgroup: either one tile decoded from blockIdx (plain launches) or a host-built static
   // schedule (longest-processing-time assignment of tiles to a fixed number of resident workgroups, see hbegp.cpp).
@@ -173,9 +175,10 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   const size_t a_step = akm ? (size_t)BK * lda : (size_t)BK, b_step = bkm ? (size_t)BK * ldb : (size_t)BK;
   const size_t a_qs = (size_t)a_rpp * lda, b_qs = (size_t)b_rpp * ldb;
 
-  vec_t ra[NCH], rb[NCH];
+  // two register sets: the loads of stage s+2 are in flight while stage s is computed and stage s+1 sits in LDS
+  vec_t ra0[NCH], rb0[NCH], ra1[NCH], rb1[NCH];
 
-  auto load_stage = [&](int s) {
+  auto load_stage = [&](int s, vec_t (&ra)[NCH], vec_t (&rb)[NCH]) {
 #pragma unroll
     for (int q = 0; q < NCH; ++q) ra[q] = *reinterpret_cast<const vec_t*>(pA + q * a_qs);
 #pragma unroll
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, vec_t (&ra)[NCH], vec_t (&rb)[NCH]) {
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
       C::lds_store(lds + buf * G::LDSE + a_lds0 + q * a_ldsq, ra[q]);
@@ -224,15 +227,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   const int fa0 = (wm * (TILE / 2) + (lane & 15)) * soA + (lane >> 4) * skA;
   const int fb0 = 2 * G::LDSE + (wn * (TILE / 2) + (lane & 15)) * soB + (lane >> 4) * skB;
 
-  if (nstages > 0) {
-    load_stage(0);
-    store_stage(0);
-  }
-  __syncthreads();
-
-  for (int s = 0; s < nstages; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nstages) load_stage(s + 1);
+  auto compute_stage = [&](int buf) {
     const int ia = buf * G::LDSE + fa0, ib = buf * G::LDSE + fb0;
 #pragma unroll
     for (int k4 = 0; k4 < BK / 4; ++k4) {
@@ -246,11 +241,48 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = C::mfma(af[a], bf[b], acc[a][b]);
     }
-    if (s + 1 < nstages) store_stage(buf ^ 1);
+  };
+
+  if constexpr (TILE == 128) {
+    // one register set (the 128-tile already holds 128 accumulator registers): loads of stage s+1 fly during stage s
+    if (nstages > 0) {
+      load_stage(0, ra0, rb0);
+      store_stage(0, ra0, rb0);
+    }
     __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nstages) load_stage(s + 1, ra0, rb0);
+      compute_stage(buf);
+      if (s + 1 < nstages) store_stage(buf ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
+    if (nstages > 0) {
+      load_stage(0, ra0, rb0);
+      if (nstages > 1) load_stage(1, ra1, rb1);
+      store_stage(0, ra0, rb0);
+    }
+    __syncthreads();
+    // steady state, unrolled by two so that the register sets are indexed statically:
+    //   even s: loads(s+2) -> set 0 | compute LDS[0] | set 1 (stage s+1) -> LDS[1] | barrier
+    //   odd  s: loads(s+2) -> set 1 | compute LDS[1] | set 0 (stage s+1) -> LDS[0] | barrier
+    for (int s = 0; s < nstages; s += 2) {
+      if (s + 2 < nstages) load_stage(s + 2, ra0, rb0);
+      compute_stage(0);
+      if (s + 1 < nstages) store_stage(1, ra1, rb1);
+      __syncthreads();
+      if (s + 1 >= nstages) break;
+      if (s + 3 < nstages) load_stage(s + 3, ra1, rb1);
+      compute_stage(1);
+      if (s + 2 < nstages) store_stage(0, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   // epilogue
+  if (bad != 0) return;
   T* Cg = static_cast<T*>(op.C);
   const int row0 = ti * TILE + wm * (TILE / 2), col0 = tj * TILE + wn * (TILE / 2) + (lane & 15);
 #pragma unroll
@@ -659,29 +691,45 @@ __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv,
   if (sgrp == 0) part[(size_t)chunk * np + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// alpha_j = sum_chunks part[c][j]; per-workgroup partial sums of y^T alpha and sum log L_jj  (256 columns per workgroup)
 template <typename T>
-__global__ void __launch_bounds__(256) finalize_lml_kernel(const double* __restrict__ part, int nchunks, int np, int n,
+__global__ void __launch_bounds__(256) alpha_reduce_kernel(const double* __restrict__ part, int nchunks, int np, int n,
                                                            const T* __restrict__ y, const T* __restrict__ ldiag,
-                                                           T* __restrict__ alpha, EvalOut* out, const int* info) {
+                                                           T* __restrict__ alpha, double* __restrict__ sums, const int* info) {
   if (*info != 0) return;
   __shared__ double red[4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
   double ya = 0, ld = 0;
-  for (int j = threadIdx.x; j < np; j += 256) {
+  if (j < np) {
     double a = 0;
     for (int c = j / 256; c < nchunks; ++c) a += part[(size_t)c * np + j];
     const T at = (T)a;
     alpha[j] = (j < n) ? at : T(0);
     if (j < n) {
-      ya += (double)y[j] * (double)at;
-      ld += log((double)ldiag[j]);
+      ya = (double)y[j] * (double)at;
+      ld = log((double)ldiag[j]);
     }
   }
   const double s1 = block_sum(ya, red);
   const double s2 = block_sum(ld, red);
   if (threadIdx.x == 0) {
+    sums[2 * blockIdx.x] = s1;
+    sums[2 * blockIdx.x + 1] = s2;
+  }
+}
+
+// lml = -1/2 y^T alpha - sum log L_ii - n/2 log(2 pi)   (lml.rs:57-59); fixed summation order
+__global__ void lml_final_kernel(const double* __restrict__ sums, int nblocks, int n, EvalOut* out, const int* info) {
+  if (*info != 0) return;
+  if (threadIdx.x == 0) {
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      s1 += sums[2 * b];
+      s2 += sums[2 * b + 1];
+    }
     out->yalpha = s1;
     out->logdet = s2;
-    out->lml = -0.5 * s1 - s2 - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);  // lml.rs:57-59
+    out->lml = -0.5 * s1 - s2 - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
   }
 }
 
@@ -691,7 +739,11 @@ void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, 
   hipLaunchKernelGGL((trmv_n_kernel<T>), dim3(np / 4), dim3(256), 0, s, Xinv, np, n, y, wbuf, info);
   const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
   hipLaunchKernelGGL((trmv_t_kernel<T>), dim3(np / 64, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info);
-  hipLaunchKernelGGL((finalize_lml_kernel<T>), dim3(1), dim3(256), 0, s, part, nchunks, np, n, y, ldiag, alpha, out, info);
+  // the per-workgroup sums live behind the chunk partials (part has room for nchunks*np + 2*np/256 doubles)
+  double* sums = part + (size_t)nchunks * np;
+  const int nblocks = (np + 255) / 256;
+  hipLaunchKernelGGL((alpha_reduce_kernel<T>), dim3(nblocks), dim3(256), 0, s, part, nchunks, np, n, y, ldiag, alpha, sums, info);
+  hipLaunchKernelGGL(lml_final_kernel, dim3(1), dim3(64), 0, s, sums, nblocks, n, out, info);
 }
 template void launch_alpha_lml<double>(const double*, int, int, const double*, const double*, double*, double*, double*,
                                        EvalOut*, const int*, hipStream_t);

@@ -77,3 +77,32 @@ def test_f32_oracle_tracks_f64():
     r32 = O.lml_with_gradient(g["X"].astype(np.float32), g["y"].astype(np.float32), s2, c, ell, 2.5)
     assert r32["alpha"].dtype == np.float32
     assert abs(r32["lml"] - float(g["lml"])) < 5e-2
+
+
+# ---- the plain-C oracle (no LAPACK) against the same goldens and against the numpy/LAPACK oracle -------------------
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_c_oracle_matches_sklearn_golden(path):
+    from oracle import c_oracle
+
+    g = np.load(path)
+    X, y, theta, nu = g["X"], g["y"], g["theta"], float(g["nu"])
+    s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+    res = c_oracle.lml_with_gradient(X, y, s2, c, ell, nu)
+    assert res is not None
+    assert abs(res["lml"] - float(g["lml"])) <= 1e-10 * max(1.0, abs(float(g["lml"])))
+    np.testing.assert_allclose(res["grad"], g["grad"], rtol=0, atol=1e-9 * max(1.0, np.abs(g["grad"]).max()))
+    np.testing.assert_allclose(res["alpha"], g["alpha"], rtol=0, atol=1e-9 * np.abs(g["alpha"]).max())
+    mean, var, warn = c_oracle.predict(g["Xs"], X, res["alpha"], res["k_inv"], c, ell, nu)
+    np.testing.assert_allclose(mean, g["mean"], rtol=0, atol=1e-9 * max(1.0, np.abs(g["mean"]).max()))
+    np.testing.assert_allclose(var, g["var"], rtol=0, atol=1e-9 * c)
+    assert warn == 0
+    ref = O.lml_with_gradient(X, y, s2, c, ell, nu)
+    np.testing.assert_allclose(res["k_inv"], ref["k_inv"], rtol=0, atol=1e-9 * np.abs(ref["k_inv"]).max())
+
+
+def test_c_oracle_not_pd():
+    from oracle import c_oracle
+
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
+    y = np.array([1.0, 2.0, 3.0])
+    assert c_oracle.lml_with_gradient(X, y, 1e-300, 1.0, [1.0, 1.0], 2.5) is None
