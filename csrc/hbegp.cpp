@@ -175,13 +175,16 @@ static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, st
       }
   }
   const int ntiles = (int)its.size();
-  const int occmax = tile == 128 ? 2 : 4;
+  // resident workgroups per CU the kernel can reach (registers: 206 / 168 VGPRs for the 128- / 64-tile kernels)
+  static const int occ_env = env_int("HBEGP_SCHED_OCC", 0);
+  const int occmax = occ_env > 0 ? occ_env : 2;  // measured at n=4096 (64-tiles): 2 per CU 49 TFLOP/s, 3 per CU 37, 1 per CU 40
   // Above ~2 tiles per resident slot the hardware dispatcher (tiles are listed deepest-first) balances better than a
   // static list (measured: LAUUM at n=4096, 2080 tiles: 50 vs 47 TFLOP/s); below it the static list wins (TRSM 29 -> 44).
   int nwg = 0;
-  if (ntiles < 2 * 256 * occmax)
-    for (int cand = 256 * occmax; cand >= 256; cand /= 2)
-      if (ntiles >= 2 * cand) { nwg = cand; break; }
+  static const int sched_max_tiles = env_int("HBEGP_SCHED_MAXTILES", 2048);
+  if (ntiles < sched_max_tiles)
+    for (int occ = occmax; occ >= 1; --occ)
+      if (ntiles >= 2 * 256 * occ) { nwg = 256 * occ; break; }
   static const int sched_on = env_int("HBEGP_SCHED", 1);
   if (!sched_on || nwg == 0) return false;
   std::stable_sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.w > b.w; });

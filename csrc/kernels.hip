@@ -73,7 +73,10 @@ struct GemmGeom {
   using C = Cfg<T>;
   // contraction depth per LDS stage: 128 bytes of k for the big tiles, 512 bytes for the 32-tiles (small, latency-bound
   // launches: fewer, fatter stages)
-  static constexpr int BKE = (TILE == 32 ? 4 : 1) * C::BK;
+#ifndef HBEGP_KMUL32
+#define HBEGP_KMUL32 2  /* measured in the 3-stream bench: 1 -> 1.104, 2 -> 1.127, 4 -> 1.054 fit+predict/s */
+#endif
+  static constexpr int BKE = (TILE == 32 ? HBEGP_KMUL32 : 1) * C::BK;
   static constexpr int SK = BKE + 2;          // LDS row stride, operand stored [outer][k]
   static constexpr int SM = TILE + 16;        // LDS row stride, operand stored [k][outer]
   static constexpr int LDSE = (TILE * SK > BKE * SM) ? TILE * SK : BKE * SM;  // elements per operand buffer
@@ -315,7 +318,13 @@ static void launch_gemm_t(const GemmLaunch& gl, hipStream_t s) {
   }
   if (g.sched_off) total = g.sched_nwg;
   if (total <= 0) return;
-  const size_t lds = (size_t)4 * G::LDSE * sizeof(T);
+  size_t lds = (size_t)4 * G::LDSE * sizeof(T);
+  // Static schedules assume exactly sched_nwg / 256 workgroups on every CU: pin that residency by asking for the matching
+  // share of the 160 KiB LDS (otherwise the dispatcher may stack 3 workgroups on some CUs and 1 on others).
+  if (g.sched_off && g.sched_nwg >= 256) {
+    const size_t share = ((size_t)163840 / (size_t)(g.sched_nwg / 256)) / 256 * 256;
+    if (share > lds) lds = share;
+  }
   hipLaunchKernelGGL((gemm_kernel<T, TILE>), dim3(total), dim3(256), lds, s, g);
 }
 
@@ -1060,7 +1069,7 @@ template void launch_pred_var<float>(const float*, const float*, int, int, const
 template <typename T, int TILE>
 static void init_gemm_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((size_t)4 * GemmGeom<T, TILE>::LDSE * sizeof(T)));
+                            163840);
 }
 void init_kernels() {
   init_gemm_attr<double, 128>(); init_gemm_attr<double, 64>(); init_gemm_attr<double, 32>();
