@@ -115,6 +115,16 @@ def main():
         big = "gemm128" if ph["gemm128_ms"] > 0 else "gemm64"
         achieved = ph[f"{big}_gflop"] / ph[f"{big}_ms"] if ph[f"{big}_ms"] > 0 else 0.0  # GFLOP/ms = TFLOP/s
         eval_tflops = (n ** 3) * 1e-12 / (ph["eval_graph_ms"] * 1e-3)
+        # HBM/L2-miss bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs, gfx950 read correction applied) -- counters cannot be collected from inside this process
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            k = pmc[f"hbegp::gemm_kernel<double, {big[4:]}>"]
+            if args.n is None:
+                traffic = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
+        except Exception:
+            traffic = None
         roofline = {
             "bound": "mfma",
             "kernel": f"hbegp::gemm_kernel<double,{big[4:]}>",
@@ -122,7 +132,8 @@ def main():
             "peak": PEAK_FP64_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch (mean over the kernel's launches in one evaluation; profiles/r01_pmc_traffic.json)",
             "algorithmic_gflop_per_eval": ph[f"{big}_gflop"],
             "kernel_ms_per_eval": ph[f"{big}_ms"],
             "whole_eval_ms": ph["eval_graph_ms"],
