@@ -51,12 +51,14 @@ struct GemmOp {
   int beta_one;   // beta = 1 instead of 0
 };
 
+constexpr int MAXOPS = 4;  // independent tile-GEMM operations per launch
+
 struct GemmLaunch {
-  GemmOp op[2];
+  GemmOp op[MAXOPS];
   int nops;
   const int* info;  // device flag: kernels return immediately when *info != 0
   // optional static schedule (device memory): workgroup b runs items [sched_off[b], sched_off[b+1]);
-  // item = op << 31 | local tile row << 16 | local tile col, in units of the launch tile size
+  // item = op << 30 | local tile row << 16 | local tile col, in units of the launch tile size
   const int* sched_off;
   const unsigned* sched_items;
   int sched_nwg;

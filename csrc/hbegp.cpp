@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <queue>
 #include <cmath>
@@ -171,7 +172,7 @@ static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, st
       for (int j = 0; j < (op.c_lower ? i + 1 : op.nj); ++j) {
         int ka, kb;
         tile_krange(op, op.ci0 + i, op.cj0 + j, &ka, &kb);
-        its.push_back({(double)(kb - ka) + 0.75, ((unsigned)oi << 31) | ((unsigned)i << 16) | (unsigned)j});
+        its.push_back({(double)(kb - ka) + 0.75, ((unsigned)oi << 30) | ((unsigned)i << 16) | (unsigned)j});
       }
   }
   const int ntiles = (int)its.size();
@@ -362,7 +363,7 @@ struct Problem : ProblemBase {
 
   // Cholesky + inverse of the factor on the diagonal block range [lo, hi) (units of 128): on return W2 holds
   // X = L^-1 on that range (lower), ldiag the diagonal of L.
-  void chol_inv(Slot<T>& s, size_t di, int lo, int hi, PhaseTimer* tm) {
+  void chol_inv_rec(Slot<T>& s, size_t di, int lo, int hi, PhaseTimer* tm) {
     if (hi - lo == 1) {
       if (dry_) return;
       if (tm) tm->begin(PhaseTimer::LEAF);
@@ -371,7 +372,7 @@ struct Problem : ProblemBase {
       return;
     }
     const int mid = lo + (hi - lo) / 2;
-    chol_inv(s, di, lo, mid, tm);
+    chol_inv_rec(s, di, lo, mid, tm);
     GemmOp base{};
     base.lda = base.ldb = base.ldc = np;
     {
@@ -403,7 +404,7 @@ struct Problem : ProblemBase {
       u.k0 = lo; u.k1 = mid; u.klim = 2; u.maskB = 1;
       gemm(s, di, g, tm, PhaseTimer::GEMM);
     }
-    chol_inv(s, di, mid, hi, tm);
+    chol_inv_rec(s, di, mid, hi, tm);
     {
       // X21 = -X22 * U -> W2[2,1]
       GemmLaunch g{};
@@ -418,6 +419,77 @@ struct Problem : ProblemBase {
     }
   }
 
+  // Top of the factorisation.  Above `big` (in 128-blocks) the binary recursion would issue a chain of mid-size,
+  // poorly filled launches; instead the big blocks are swept right-looking (one TRSM and one SYRK per big block, each
+  // covering everything below / behind it) and the off-diagonal blocks of X = L^-1 are formed afterwards level by level,
+  // all nodes of a level in one launch (they are independent: TRTRI has no dependency along the diagonal).
+  void chol_inv(Slot<T>& s, size_t di, int nb, PhaseTimer* tm) {
+    static const int big_env = env_int("HBEGP_NBIG", 1 << 20);  // measured at n=4096: 8 -> 3.55 ms, 4 -> 3.56, off (binary recursion only) -> 3.43
+    const int big = std::max(1, big_env);
+    const int nbb = (nb + big - 1) / big;
+    if (nbb <= 1) {
+      chol_inv_rec(s, di, 0, nb, tm);
+      return;
+    }
+    GemmOp base{};
+    base.lda = base.ldb = base.ldc = np;
+    for (int k = 0; k < nbb; ++k) {
+      const int lo = k * big, hi = std::min(nb, lo + big);
+      chol_inv_rec(s, di, lo, hi, tm);
+      if (hi >= nb) break;
+      {
+        // T[:, k] = A[:, k] * X_kk^T for every block row below  -> W2
+        GemmLaunch g{};
+        g.nops = 1;
+        GemmOp& op = g.op[0];
+        op = base;
+        op.A = s.W1; op.B = s.W2; op.C = s.W2;
+        op.ci0 = hi; op.mi = nb - hi; op.cj0 = lo; op.nj = hi - lo;
+        op.k0 = lo; op.k1 = hi; op.klim = 1; op.maskB = 1;
+        gemm(s, di, g, tm, PhaseTimer::GEMM);
+      }
+      {
+        // trailing update: A[i,j] -= T[i,k] T[j,k]^T, k < j <= i (lower)
+        GemmLaunch g{};
+        g.nops = 1;
+        GemmOp& op = g.op[0];
+        op = base;
+        op.A = s.W2; op.B = s.W2; op.C = s.W1;
+        op.ci0 = hi; op.cj0 = hi; op.mi = nb - hi; op.nj = nb - hi; op.c_lower = 1;
+        op.k0 = lo; op.k1 = hi; op.alpha_neg = 1; op.beta_one = 1;
+        gemm(s, di, g, tm, PhaseTimer::GEMM);
+      }
+    }
+    // off-diagonal blocks of X above the big-block level: X21 = -X22 * (T * X11), bottom-up over a binary tree of big blocks
+    for (int span = 1; span < nbb; span *= 2) {
+      std::vector<std::array<int, 3>> nodes;  // (lo, mid, hi) in 128-blocks
+      for (int a = 0; a + span < nbb; a += 2 * span)
+        nodes.push_back({a * big, std::min(nb, (a + span) * big), std::min(nb, (a + 2 * span) * big)});
+      for (size_t n0 = 0; n0 < nodes.size(); n0 += MAXOPS) {
+        const int cnt = (int)std::min<size_t>(MAXOPS, nodes.size() - n0);
+        GemmLaunch gu{}, gx{};
+        gu.nops = gx.nops = cnt;
+        for (int q = 0; q < cnt; ++q) {
+          const int lo = nodes[n0 + q][0], mid = nodes[n0 + q][1], hi = nodes[n0 + q][2];
+          GemmOp& u = gu.op[q];  // U = T * X11 -> W1[2,1]
+          u = base;
+          u.A = s.W2; u.B = s.W2; u.C = s.W1;
+          u.a_kmajor = 0; u.b_kmajor = 1;
+          u.ci0 = mid; u.mi = hi - mid; u.cj0 = lo; u.nj = mid - lo;
+          u.k0 = lo; u.k1 = mid; u.klim = 2; u.maskB = 1;
+          GemmOp& x = gx.op[q];  // X21 = -X22 * U -> W2[2,1]
+          x = base;
+          x.A = s.W2; x.B = s.W1; x.C = s.W2;
+          x.a_kmajor = 0; x.b_kmajor = 1;
+          x.ci0 = mid; x.mi = hi - mid; x.cj0 = lo; x.nj = mid - lo;
+          x.k0 = mid; x.k1 = hi; x.klim = 3; x.maskA = 1; x.alpha_neg = 1;
+        }
+        gemm(s, di, gu, tm, PhaseTimer::GEMM);
+        gemm(s, di, gx, tm, PhaseTimer::GEMM);
+      }
+    }
+  }
+
   void enqueue_eval(Slot<T>& s, size_t di, int target, bool want_grad, PhaseTimer* tm) {
     const int nb = np / NB;
     s.gemm_ord = 0;
@@ -429,7 +501,7 @@ struct Problem : ProblemBase {
       launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
       if (tm) tm->end();
     }
-    chol_inv(s, di, 0, nb, tm);
+    chol_inv(s, di, nb, tm);
     if (!dry_) {
       if (tm) tm->begin(PhaseTimer::ALPHA);
       launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);

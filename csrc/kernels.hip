@@ -115,14 +115,14 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   int oi = 0, li, lj;
   if (g.sched_off) {
     const unsigned item = g.sched_items[it];
-    oi = item >> 31;
-    li = (item >> 16) & 0x7fff;
+    oi = item >> 30;
+    li = (item >> 16) & 0x3fff;
     lj = item & 0xffff;
   } else {
     int bid = blockIdx.x;
-    if (g.nops > 1 && bid >= g.op[0].ntiles) {
-      oi = 1;
-      bid -= g.op[0].ntiles;
+    while (oi + 1 < g.nops && bid >= g.op[oi].ntiles) {
+      bid -= g.op[oi].ntiles;
+      ++oi;
     }
     const GemmOp& o = g.op[oi];
     if (o.reverse) bid = o.ntiles - 1 - bid;  // heaviest tiles first
@@ -352,9 +352,18 @@ struct LeafGeom {
   static constexpr int S = 130;          // LDS row stride of the block image
   static constexpr int YS = 18;          // row stride of a 16x16 sub-block image
   static constexpr int YB = 16 * YS;     // elements per 16x16 image
-  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 8 * YB + 4 * YB) * sizeof(T);
+  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 8 * YB + 4 * YB + 128) * sizeof(T);
 };
 
+// Structure (8 panels of 16 columns, one barrier-separated phase sequence per panel p):
+//   (A) wave 0 owns rows 16p .. 16p+63 (lane = row) and eliminates the panel in registers with lane broadcasts
+//       (v_readlane): this factors the 16x16 diagonal block AND solves the triangular system for the next three block
+//       rows in the same instruction stream.  No inverse of the diagonal block is needed on the critical path.
+//       Meanwhile waves 1-3: trailing update of panel p-1 (block columns >= p+1), Y_{p-1} = L_{p-1,p-1}^-1 by forward
+//       substitution (lane = column), block row p-2 of X = L^-1 on MFMA.
+//   (B) p < 4 only: wave 1 solves the rows beyond wave 0's window by substitution against L_pp (LDS broadcast reads)
+//       while waves 0,2,3 update the window rows of block column p+1;   (C) the remaining blocks of column p+1.
+// Tail: Y_7, block rows 6 and 7 of X.  fp64 MFMA for every 16x16x16 product.
 template <typename T>
 __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __restrict__ W2, int ld, int blk,
                                                    T* __restrict__ ldiag, int* info, int dbg) {
@@ -369,6 +378,7 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
   T* As = reinterpret_cast<T*>(smem_raw);  // [128][S]: lower = A -> L ; strict upper blocks = X^T
   T* Ys = As + 128 * S;                    // [8][16][YS]: inverses of the diagonal 16x16 factors
   T* Sc = Ys + 8 * YB;                     // [4][16][YS]: per-wave scratch
+  T* Rd = Sc + 4 * YB;                     // [128]: 1 / L_kk
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m16 = lane & 15, q4 = lane >> 4;
@@ -401,10 +411,6 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
   }
   __syncthreads();
 
-  // ---------------- phase 1: blocked right-looking Cholesky, 16-wide panels, look-ahead of one panel ----------------
-  // Per panel p:  (A) wave 0 factors the 16x16 diagonal block (registers + lane broadcasts) while waves 1-3 finish the
-  //               trailing update of panel p-1 on block columns >= p+1;
-  //               (B) all waves: L[i,p] = A[i,p] Y_pp^T;  (C) all waves: update of block column p+1 only.
   auto update_block = [&](int i, int j, int pp) {  // A[i,j] -= L[i,pp] L[j,pp]^T
     acc_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -459,62 +465,75 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
     }
   };
 
+  // Y_q = L_qq^-1 by forward substitution, lane j (< 16) owns column j; L entries are LDS broadcast reads
+  auto yinv_block = [&](int q) {
+    const int j = m16;
+    T y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      T sacc = (i == j) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc = __builtin_fma(-As[(q * 16 + i) * S + q * 16 + k], y[k], sacc);
+      y[i] = sacc * Rd[q * 16 + i];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Ys[q * YB + i * YS + j] = y[i];
+    }
+  };
+
   for (int p = 0; p < 8; ++p) {
-    if (wave == 0 && !(dbg & 1)) {
-      // 16x16 diagonal block: lane r (and its 3 replicas) owns row r of [A | I]; forward elimination gives L and L^-1.
-      // No per-lane predicates on the A side: entries above the diagonal only ever feed themselves.
-      const int r = m16;
-      T a[16], tv[16];
+    if (wave == 0) {
+      if (!(dbg & 1)) {
+        const int nwin = min(64, 128 - 16 * p);
+        const int row = 16 * p + ((lane < nwin) ? lane : 0);
+        T a[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        a[j] = As[(p * 16 + r) * S + p * 16 + j];
-        tv[j] = (j == r) ? T(1) : T(0);
-      }
-      bool bad = false;
-      T rinv_own = T(0);
+        for (int j = 0; j < 16; ++j) a[j] = As[row * S + p * 16 + j];
+        bool bad = false;
+        T rinv_own = T(0);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const T piv = readlane(a[k], k);
-        bad = bad || !(piv > T(0));
-        // 1/sqrt(piv): hardware estimate + two Newton steps (full double precision)
-        T rinv = __builtin_amdgcn_rsq(piv);
+        for (int k = 0; k < 16; ++k) {
+          const T piv = readlane(a[k], k);
+          bad = bad || !(piv > T(0));
+          // 1/sqrt(piv): hardware estimate + two Newton steps (full double precision)
+          T rinv = __builtin_amdgcn_rsq(piv);
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const T gg = piv * rinv, hh = T(0.5) * rinv;
-          const T ee = __builtin_fma(-hh, gg, T(0.5));
-          rinv = __builtin_fma(rinv, ee, rinv);
+          for (int it = 0; it < 2; ++it) {
+            const T gg = piv * rinv, hh = T(0.5) * rinv;
+            const T ee = __builtin_fma(-hh, gg, T(0.5));
+            rinv = __builtin_fma(rinv, ee, rinv);
+          }
+          const T lk = a[k] * rinv;  // l_{row,k} for rows at or below the pivot (pivot row: sqrt(piv))
+          a[k] = lk;
+          rinv_own = (lane == k) ? rinv : rinv_own;
+          // entries above the diagonal of the 16x16 block only ever feed themselves: no per-lane predicates needed
+#pragma unroll
+          for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, readlane(lk, j), a[j]);
         }
-        const T lk = a[k] * rinv;  // l_{r,k} for r >= k (for r == k: sqrt(piv))
-        a[k] = lk;
-        rinv_own = (r == k) ? rinv : rinv_own;
+        if (lane < nwin) {
 #pragma unroll
-        for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, readlane(lk, j), a[j]);
-        // inverse side on the un-normalised rows t: rows r > k get t_r -= l_rk * (t_k / l_kk); rows <= k are final
-        const T lkm = (r > k) ? lk * rinv : T(0);
-#pragma unroll
-        for (int j = 0; j <= k; ++j) tv[j] = __builtin_fma(-lkm, readlane(tv[j], k), tv[j]);
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j <= r) As[(p * 16 + r) * S + p * 16 + j] = a[j];
-          Ys[p * YB + r * YS + j] = (j <= r) ? tv[j] * rinv_own : T(0);
+          for (int j = 0; j < 16; ++j)
+            if (lane >= 16 || j <= lane) As[row * S + p * 16 + j] = a[j];
         }
-        T dv = T(0);
+        if (lane < 16) {
+          T dv = T(0);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dv = (j == r) ? a[j] : dv;
-        ldiag[blk * NB + p * 16 + r] = dv;
+          for (int j = 0; j < 16; ++j) dv = (j == lane) ? a[j] : dv;
+          ldiag[blk * NB + p * 16 + lane] = dv;
+          Rd[p * 16 + lane] = rinv_own;
+        }
+        if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
       }
-      if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
-    } else if (p > 0 && wave > 0) {
-      // waves 1-3 meanwhile: block row p-1 of the inverse, then the rest of the trailing update of panel p-1
-      // (blocks (i,j), p+1 <= j <= i <= 7); one combined work list dealt round-robin
-      const int nx = (dbg & 2) ? 0 : p - 1;
+    } else if (p > 0) {
+      // waves 1-3 meanwhile: Y_{p-1} (wave 3), block row p-2 of the inverse, rest of the trailing update of panel p-1
+      if (wave == 3 && !(dbg & 2)) yinv_block(p - 1);
+      const int nx = ((dbg & 2) || p < 3) ? 0 : p - 2;
       const int tcount = 7 - p;
       const int nupd = (dbg & 4) ? 0 : tcount * (tcount + 1) / 2;
       for (int idx = wave - 1; idx < nx + nupd; idx += 3) {
         if (idx < nx) {
-          xinv_block(p - 1, idx);
+          xinv_block(p - 2, idx);
         } else {
           const int u = idx - nx;
           const int li = tri_row(u), lj = u - li * (li + 1) / 2;
@@ -524,30 +543,51 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
     }
     __syncthreads();
     if (p == 7) break;
+    if (dbg & 4) continue;
 
-    // (B) panel: L[i,p] = A[i,p] * Y_pp^T, i > p
-    for (int i = p + 1 + wave; i < 8 && !(dbg & 4); i += 4) {
-      acc_t acc = {0, 0, 0, 0};
+    if (p < 4) {
+      // (B) rows beyond wave 0's window (blocks p+4 .. 7): substitution against L_pp, lane = row
+      if (wave == 1) {
+        const int nfar = 64 - 16 * p;
+        const int row = 16 * p + 64 + ((lane < nfar) ? lane : 0);
+        T a[16];
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const T af = As[(i * 16 + m16) * S + p * 16 + k4 * 4 + q4];
-        const T bf = Ys[p * YB + m16 * YS + k4 * 4 + q4];
-        acc = C::mfma(af, bf, acc);
+        for (int j = 0; j < 16; ++j) a[j] = As[row * S + p * 16 + j];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const T lk = a[k] * Rd[p * 16 + k];
+          a[k] = lk;
+#pragma unroll
+          for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, As[(p * 16 + j) * S + p * 16 + k], a[j]);
+        }
+        if (lane < nfar) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) As[row * S + p * 16 + j] = a[j];
+        }
+      } else {
+        // window rows of block column p+1: blocks p+1 .. p+3, one per wave (0, 2, 3)
+        const int slot = wave == 0 ? 0 : wave - 1;
+        update_block(p + 1 + slot, p + 1, p);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) As[(i * 16 + C::crow(lane, r)) * S + p * 16 + m16] = acc[r];
+      __syncthreads();
+      // (C) far rows of block column p+1: blocks p+4 .. 7
+      for (int i = p + 4 + wave; i < 8; i += 4) update_block(i, p + 1, p);
+      __syncthreads();
+    } else {
+      // (C) block column p+1: every remaining row is inside the window
+      for (int i = p + 1 + wave; i < 8; i += 4) update_block(i, p + 1, p);
+      __syncthreads();
     }
-    __syncthreads();
-
-    // (C) block column p+1 only: A[i,p+1] -= L[i,p] L[p+1,p]^T, i >= p+1
-    for (int i = p + 1 + wave; i < 8 && !(dbg & 4); i += 4) update_block(i, p + 1, p);
-    __syncthreads();
   }
 
-  // ---------------- tail of the inverse: block row 7 (rows 0..6 were produced inside the panel loop) ----------------
-  if (!(dbg & 2))
+  // ---------------- tail of the inverse: Y_7 and block row 6 of X, then block row 7 ----------------
+  if (!(dbg & 2)) {
+    if (wave == 3) yinv_block(7);
+    else for (int j = wave; j < 6; j += 3) xinv_block(6, j);
+    __syncthreads();
     for (int j = wave; j < 7; j += 4) xinv_block(7, j);
-  __syncthreads();
+    __syncthreads();
+  }
   // diagonal sub-blocks of X
   for (int c = t; c < 8 * 256; c += 256) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
