@@ -74,6 +74,59 @@ struct hbegp_ctx {
   std::vector<int> devs;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device-memory pool for the large work matrices (np x np).  hipMalloc/hipFree of 128 MiB blocks costs tens of
+// milliseconds per fit; the caller fits one model per generation with slowly growing n, so blocks are recycled by
+// exact size.  Recycled blocks hold finite numbers from their previous life, which is all the engine requires of
+// never-written regions (strict upper triangles).
+#include <map>
+struct DevPool {
+  std::mutex mu;
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_list;
+  size_t cached = 0;
+  static constexpr size_t MAX_CACHED = (size_t)24 << 30;
+  void* get(int dev, size_t bytes, bool* fresh) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_list.find({dev, bytes});
+      if (it != free_list.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        cached -= bytes;
+        *fresh = false;
+        return p;
+      }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      trim();  // give cached blocks back and retry once
+      e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) throw HipError{e, "hipMalloc (pool)", __LINE__};
+    }
+    *fresh = true;
+    return p;
+  }
+  void put(int dev, void* p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cached + bytes > MAX_CACHED) {
+      (void)hipFree(p);
+      return;
+    }
+    free_list[{dev, bytes}].push_back(p);
+    cached += bytes;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_list)
+      for (void* p : kv.second) (void)hipFree(p);
+    free_list.clear();
+    cached = 0;
+  }
+};
+static DevPool g_pool;
+
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // theta (log space) -> clamped linear-space parameters (fit.rs:94-96)
@@ -114,7 +167,9 @@ struct PhaseTimer {
 static int pick_tile(int tiles128) {
   static const int forced = env_int("HBEGP_TILE", 0);
   if (forced == 32 || forced == 64 || forced == 128) return forced;
-  if (tiles128 >= env_int("HBEGP_T128_MIN", 2048)) return 128;  // n >= 16384: below that 64-tiles balance better (measured)
+  // 128-tiles only when a launch has >= 600 of them (n >= 8192): measured n=8192 15.1 -> 13.7 ms/evaluation with them,
+  // n=4096 LAUUM (528 tiles) 0.44 ms with 64-tiles vs 0.77 ms with 128-tiles
+  if (tiles128 >= env_int("HBEGP_T128_MIN", 600)) return 128;
   if (tiles128 >= env_int("HBEGP_T64_MIN", 100)) return 64;
   return 32;
 }
@@ -270,16 +325,17 @@ struct Problem : ProblemBase {
       for (auto& s : slots[di]) {
         s.dev = c->devs[di];
         HIPCHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        HIPCHECK(hipMalloc(&s.W1, sizeof(T) * nn));
-        HIPCHECK(hipMalloc(&s.W2, sizeof(T) * nn));
+        bool fresh1 = false, fresh2 = false, fk = false;
+        s.W1 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh1));
+        s.W2 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh2));
         for (int b = 0; b < 2; ++b) {
-          HIPCHECK(hipMalloc(&s.Kinv[b], sizeof(T) * nn));
+          s.Kinv[b] = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fk));
           HIPCHECK(hipMalloc(&s.alpha[b], sizeof(T) * np));
         }
-        // W2's strict upper part is never written by the engine but full tiles of it are loaded (and masked) by
-        // the GEMM loader: keep it finite.
-        HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
-        HIPCHECK(hipMemset(s.W1, 0, sizeof(T) * nn));
+        // Strict upper parts are never written by the engine but whole tiles of them are loaded (and masked, or
+        // multiplied by masked zeros) by the GEMM loader: they must hold finite numbers.
+        if (fresh2) HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
+        if (fresh1) HIPCHECK(hipMemset(s.W1, 0, sizeof(T) * nn));
         HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.part_t, sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64)));
@@ -311,8 +367,9 @@ struct Problem : ProblemBase {
         for (int a = 0; a < 2; ++a)
           for (int b = 0; b < 2; ++b)
             if (s.graph[a][b]) (void)hipGraphExecDestroy(s.graph[a][b]);
-        (void)hipFree(s.W1); (void)hipFree(s.W2);
-        for (int b = 0; b < 2; ++b) { (void)hipFree(s.Kinv[b]); (void)hipFree(s.alpha[b]); }
+        const size_t nnb = sizeof(T) * (size_t)np * np;
+        g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb);
+        for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
         (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
         (void)hipFree(s.dP); (void)hipFree(s.dOut);
         (void)hipHostFree(s.hP); (void)hipHostFree(s.hOut);
@@ -325,6 +382,7 @@ struct Problem : ProblemBase {
   }
 
   void gemm(Slot<T>& s, size_t di, GemmLaunch& g, PhaseTimer* tm, int kind) {
+    hipStream_t stream = s.stream;
     g.info = &s.dOut->info;
     const int ord = s.gemm_ord++;
     if (dry_) {
@@ -357,7 +415,7 @@ struct Problem : ProblemBase {
     if (tm)
       for (int i = 0; i < g.nops; ++i) gf += op_gflop(g.op[i]);
     if (tm) tm->begin(kind, sc.tile, gf);
-    launch_gemm<T>(g, sc.tile, s.stream);
+    launch_gemm<T>(g, sc.tile, stream);
     if (tm) tm->end();
   }
 
@@ -388,7 +446,9 @@ struct Problem : ProblemBase {
       gemm(s, di, g, tm, PhaseTimer::GEMM);
     }
     {
-      // A22 -= T T^T (lower)   and   U = T * X11 -> W1[2,1]   (independent: one launch)
+      // A22 -= T T^T (lower)   and   U = T * X11 -> W1[2,1]   (independent: one launch, one static schedule).
+      // Measured alternatives at n=4096: two launches 3.71 ms/evaluation, U forked onto a second stream inside the graph
+      // 3.57 ms but 0.76 fit+predict/s in the 3-run bench (multi-branch graphs serialise badly); merged 3.38 ms, 1.10.
       GemmLaunch g{};
       g.nops = 2;
       GemmOp& syrk = g.op[0];
@@ -651,6 +711,7 @@ struct hbegp_model {
   double lml = 0;
   std::vector<double> theta;  // clamped, log space
   void *X = nullptr, *alpha = nullptr, *Kinv = nullptr;  // device
+  size_t kinv_bytes = 0;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
   hipStream_t stream = nullptr;
@@ -661,7 +722,7 @@ struct hbegp_model {
   ~hbegp_model() {
     (void)hipSetDevice(dev);
     if (stream) (void)hipStreamSynchronize(stream);
-    (void)hipFree(X); (void)hipFree(alpha); (void)hipFree(Kinv); (void)hipFree(dP); (void)hipFree(dOut);
+    (void)hipFree(X); (void)hipFree(alpha); g_pool.put(dev, Kinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
     (void)hipFree(Xs); (void)hipFree(Ks); (void)hipFree(Q); (void)hipFree(mean); (void)hipFree(var);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -678,7 +739,7 @@ static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double
   HIPCHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   HIPCHECK(hipMalloc(&m->X, sizeof(T) * (size_t)prob.n * prob.d));
   HIPCHECK(hipMalloc(&m->alpha, sizeof(T) * prob.np));
-  HIPCHECK(hipMalloc(&m->Kinv, sizeof(T) * nn));
+  { bool fr; m->Kinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->kinv_bytes = sizeof(T) * nn; }
   HIPCHECK(hipMalloc(&m->dP, sizeof(EvalParams)));
   HIPCHECK(hipMalloc(&m->dOut, sizeof(EvalOut)));
   const int b = s.best_idx < 0 ? s.last_target : s.best_idx;
@@ -940,7 +1001,10 @@ int hbegp_ctx_create(int n_devices, const int* device_ids, hbegp_ctx** out) {
   return HBEGP_OK;
   GUARD_END
 }
-void hbegp_ctx_destroy(hbegp_ctx* ctx) { delete ctx; }
+void hbegp_ctx_destroy(hbegp_ctx* ctx) {
+  g_pool.trim();
+  delete ctx;
+}
 
 int hbegp_problem_create_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, int n_slots,
                              hbegp_problem** out) {
