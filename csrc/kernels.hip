@@ -76,7 +76,10 @@ struct GemmGeom {
 #ifndef HBEGP_KMUL32
 #define HBEGP_KMUL32 2  /* measured in the 3-stream bench: 1 -> 1.104, 2 -> 1.127, 4 -> 1.054 fit+predict/s */
 #endif
-  static constexpr int BKE = (TILE == 32 ? HBEGP_KMUL32 : 1) * C::BK;
+#ifndef HBEGP_KMUL64
+#define HBEGP_KMUL64 1
+#endif
+  static constexpr int BKE = (TILE == 32 ? HBEGP_KMUL32 : (TILE == 64 ? HBEGP_KMUL64 : 1)) * C::BK;
   static constexpr int SK = BKE + 2;          // LDS row stride, operand stored [outer][k]
   static constexpr int SM = TILE + 16;        // LDS row stride, operand stored [k][outer]
   static constexpr int LDSE = (TILE * SK > BKE * SM) ? TILE * SK : BKE * SM;  // elements per operand buffer
