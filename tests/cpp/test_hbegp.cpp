@@ -1,0 +1,44 @@
+// C++ smoke of include/hbegp.hpp: the reference's simple fit->predict known-answer test (src/gpr/predict.rs:54-99)
+// through the C++ mirror.  Built and run by tests/test_gpu_cpp.py on the GPU box.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "hbegp.hpp"
+
+int main() {
+  using hbegp::FittedKernel;
+  hbegp::Context ctx(1);
+  const double xs[4] = {0.0, 0.5, 0.5, 1.0}, ys[4] = {0.0, 0.8, 1.2, 2.0};
+  hbegp::KernelBounds b{{0.001, 0.1, 0.1}, {1.0, 4.0, 2.0}};
+  std::vector<double> theta0 = {std::log(1.0), std::log(3.0), std::log(1.5)};
+  std::vector<double> starts;  // 4 restarts, deterministic log-uniform points
+  unsigned st = 938274;
+  for (int r = 0; r < 4; ++r)
+    for (int i = 0; i < 3; ++i) {
+      st = st * 1664525u + 1013904223u;
+      const double u = (st >> 8) / 16777216.0;
+      starts.push_back(std::log(b.lo[i]) + (std::log(b.hi[i]) - std::log(b.lo[i])) * u);
+    }
+  auto fk = FittedKernel<double>::new_(ctx, xs, ys, 4, 1, 2.5, theta0, b, starts);
+  auto copy = fk;  // Clone shares the device model
+  const double q[5] = {0.0, 0.25, 0.5, 0.75, 1.0}, want[5] = {0.0, 0.5, 1.0, 1.5, 2.0};
+  double mean[5], var[5];
+  copy.predict(q, 5, mean, var);
+  int bad = 0;
+  for (int i = 0; i < 5; ++i) {
+    if (std::fabs(mean[i] - want[i]) > 0.1) ++bad;
+    if (std::fabs(var[i] - 0.03) > 0.03) ++bad;
+  }
+  // not positive definite -> the C++ mirror throws where the reference panics (fit.rs:55)
+  const double xd[6] = {0.1, 0.2, 0.1, 0.2, 0.5, 0.5}, yd[3] = {1, 2, 3};
+  bool threw = false;
+  try {
+    FittedKernel<double>::extend(ctx, xd, yd, 3, 2, 2.5, {std::log(1e-300), 0.0, 0.0, 0.0});
+  } catch (const hbegp::NotPositiveDefinite&) {
+    threw = true;
+  }
+  std::printf("lml=%.6f amplitude=%.4f ell=%.4f noise=%.5f bad=%d threw=%d alpha0=%.4f\n", fk.lml(), fk.amplitude(), fk.length_scale()[0],
+              fk.noise(), bad, (int)threw, fk.alpha()[0]);
+  return (bad == 0 && threw) ? 0 : 1;
+}
