@@ -355,7 +355,7 @@ struct LeafGeom {
   static constexpr int S = 130;          // LDS row stride of the block image
   static constexpr int YS = 18;          // row stride of a 16x16 sub-block image
   static constexpr int YB = 16 * YS;     // elements per 16x16 image
-  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 8 * YB + 4 * YB + 128) * sizeof(T);
+  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 8 * YB + 4 * YB + 128) * sizeof(T);  // 162,816 B for f64
 };
 
 // Structure (8 panels of 16 columns, one barrier-separated phase sequence per panel p):
@@ -368,7 +368,7 @@ struct LeafGeom {
 //       while waves 0,2,3 update the window rows of block column p+1;   (C) the remaining blocks of column p+1.
 // Tail: Y_7, block rows 6 and 7 of X.  fp64 MFMA for every 16x16x16 product.
 template <typename T>
-__global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __restrict__ W2, int ld, int blk,
+__global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __restrict__ W2, int ld, int blk,
                                                    T* __restrict__ ldiag, int* info, int dbg) {
   using C = Cfg<T>;
   using L = LeafGeom<T>;
@@ -392,20 +392,20 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
   // load the block: all 16-byte chunks of a batch are issued before the first LDS store, so the loads overlap
   {
     constexpr int CPRW = 128 / VEC;             // chunks per row
-    constexpr int NCHUNK = 128 * CPRW / 256;     // chunks per thread
-    constexpr int BATCH = 16;
+    constexpr int NCHUNK = 128 * CPRW / 512;     // chunks per thread
+    constexpr int BATCH = NCHUNK < 16 ? NCHUNK : 16;
 #pragma unroll
     for (int b0 = 0; b0 < NCHUNK; b0 += BATCH) {
       vec_t buf[BATCH];
 #pragma unroll
       for (int q = 0; q < BATCH; ++q) {
-        const int c = t + 256 * (b0 + q);
+        const int c = t + 512 * (b0 + q);
         const int r = c / CPRW, cc = (c % CPRW) * VEC;
         buf[q] = *reinterpret_cast<const vec_t*>(Ablk + (size_t)r * ld + cc);
       }
 #pragma unroll
       for (int q = 0; q < BATCH; ++q) {
-        const int c = t + 256 * (b0 + q);
+        const int c = t + 512 * (b0 + q);
         const int r = c / CPRW, cc = (c % CPRW) * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = buf[q][e];
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
 
   // X = L^-1 block by block: X[i,i] = Y_ii ; X[i,j] = -Y_ii * sum_{k=j}^{i-1} L[i,k] X[k,j]  (i > j).
   // X[k,j] (k > j) is kept transposed in the upper part of As; block row i only needs rows < i, L[i,:] and Y_ii.
-  T* sc = Sc + wave * YB;
+  T* sc = Sc + ((wave - 1) & 3) * YB;  // waves 1-4 own a scratch image; only they run xinv_block
   auto xinv_block = [&](int i, int j) {
     acc_t acc = {0, 0, 0, 0};
     for (int k = j; k < i; ++k) {
@@ -529,19 +529,17 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
         if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
       }
     } else if (p > 0) {
-      // waves 1-3 meanwhile: Y_{p-1} (wave 3), block row p-2 of the inverse, rest of the trailing update of panel p-1
-      if (wave == 3 && !(dbg & 2)) yinv_block(p - 1);
+      // waves 1-7 meanwhile: Y_{p-1} (wave 7), block row p-2 of the inverse (waves 1-4, they own the scratch images),
+      // rest of the trailing update of panel p-1 (blocks (i,j), p+1 <= j <= i <= 7) dealt over all seven
+      if (wave == 7 && !(dbg & 2)) yinv_block(p - 1);
       const int nx = ((dbg & 2) || p < 3) ? 0 : p - 2;
+      if (wave <= 4)
+        for (int j = wave - 1; j < nx; j += 4) xinv_block(p - 2, j);
       const int tcount = 7 - p;
       const int nupd = (dbg & 4) ? 0 : tcount * (tcount + 1) / 2;
-      for (int idx = wave - 1; idx < nx + nupd; idx += 3) {
-        if (idx < nx) {
-          xinv_block(p - 2, idx);
-        } else {
-          const int u = idx - nx;
-          const int li = tri_row(u), lj = u - li * (li + 1) / 2;
-          update_block(p + 1 + li, p + 1 + lj, p - 1);
-        }
+      for (int u = wave - 1; u < nupd; u += 7) {
+        const int li = tri_row(u), lj = u - li * (li + 1) / 2;
+        update_block(p + 1 + li, p + 1 + lj, p - 1);
       }
     }
     __syncthreads();
@@ -569,30 +567,31 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
         }
       } else {
         // window rows of block column p+1: blocks p+1 .. p+3, one per wave (0, 2, 3)
-        const int slot = wave == 0 ? 0 : wave - 1;
-        update_block(p + 1 + slot, p + 1, p);
+        if (wave == 0 || wave == 2 || wave == 3) update_block(p + 1 + (wave == 0 ? 0 : wave - 1), p + 1, p);
       }
       __syncthreads();
       // (C) far rows of block column p+1: blocks p+4 .. 7
-      for (int i = p + 4 + wave; i < 8; i += 4) update_block(i, p + 1, p);
+      for (int i = p + 4 + wave; i < 8; i += 8) update_block(i, p + 1, p);
       __syncthreads();
     } else {
       // (C) block column p+1: every remaining row is inside the window
-      for (int i = p + 1 + wave; i < 8; i += 4) update_block(i, p + 1, p);
+      for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p);
       __syncthreads();
     }
   }
 
   // ---------------- tail of the inverse: Y_7 and block row 6 of X, then block row 7 ----------------
   if (!(dbg & 2)) {
-    if (wave == 3) yinv_block(7);
-    else for (int j = wave; j < 6; j += 3) xinv_block(6, j);
+    if (wave == 7) yinv_block(7);
+    else if (wave >= 1 && wave <= 4)
+      for (int j = wave - 1; j < 6; j += 4) xinv_block(6, j);
     __syncthreads();
-    for (int j = wave; j < 7; j += 4) xinv_block(7, j);
+    if (wave >= 1 && wave <= 4)
+      for (int j = wave - 1; j < 7; j += 4) xinv_block(7, j);
     __syncthreads();
   }
   // diagonal sub-blocks of X
-  for (int c = t; c < 8 * 256; c += 256) {
+  for (int c = t; c < 8 * 256; c += 512) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
     Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j] = Ys[pblk * YB + r * YS + j];
   }
@@ -600,7 +599,7 @@ __global__ void __launch_bounds__(256, 2) leaf_kernel(T* __restrict__ W1, T* __r
 
 template <typename T>
 void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg) {
-  hipLaunchKernelGGL((leaf_kernel<T>), dim3(1), dim3(256), LeafGeom<T>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg);
+  hipLaunchKernelGGL((leaf_kernel<T>), dim3(1), dim3(512), LeafGeom<T>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg);
 }
 template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t, int);
 template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t, int);
