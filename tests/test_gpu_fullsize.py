@@ -1,0 +1,88 @@
+"""GPU, BASELINE.json's full sizes: size-independent properties of one evaluation / model (the oracle would take minutes
+at these sizes).  K comes from the CPU oracle's kernel (independent of the device assembly kernel)."""
+import math
+
+import numpy as np
+import pytest
+
+from hbetune_rs_amd import gpr, synth
+from oracle import gpr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _theta_parts(theta):
+    return math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+
+
+@pytest.mark.parametrize("cfg", ["M", "C3", "C4", "C5"])
+def test_full_size_properties(cfg):
+    w = synth.make_workload(cfg)
+    X, y, theta = w["X"], w["y"], w["theta"].copy()
+    f32 = X.dtype == np.float32
+    if f32:
+        theta[0] = theta[1] + math.log(0.5)  # keep cond(K) moderate for f32 (see test_f32_path_himmelblau)
+    s2, c, ell = _theta_parts(theta)
+    n, d = X.shape
+    tol = 2e-3 if f32 else 1e-8
+    prob = gpr.Problem(X, y)
+    res = prob.lml_with_gradient(theta)
+    assert res is not None
+    lml, grad = res
+    alpha, _, ldiag = prob.results(want_kinv=False)
+    assert np.all(np.isfinite(alpha)) and np.all(ldiag > 0)
+
+    # (1) alpha solves (K + s2 I) alpha = y: residual relative to |y|, K from the CPU oracle in f64
+    K = O.product_kernel(X.astype(np.float64), X.astype(np.float64), c, ell, 2.5)
+    K[np.diag_indices(n)] += s2
+    r = K @ alpha.astype(np.float64) - y.astype(np.float64)
+    assert np.linalg.norm(r) <= tol * np.linalg.norm(y) * 10
+
+    # (2) the device kernel matrix equals the oracle's
+    Kd = prob.kernel_matrix(theta)
+    np.testing.assert_allclose(Kd[::97, ::89], K[::97, ::89], rtol=1e-5 if f32 else 1e-12, atol=1e-6 if f32 else 1e-14)
+
+    # (3) lml identity: -1/2 y^T alpha - sum log L_ii - n/2 log 2 pi, with log det from an independent f64 Cholesky
+    sign, logdet = np.linalg.slogdet(K)
+    want_lml = -0.5 * float(y.astype(np.float64) @ alpha.astype(np.float64)) - 0.5 * logdet - n / 2 * math.log(2 * math.pi)
+    assert abs(lml - want_lml) <= (1e-3 if f32 else 1e-9) * abs(want_lml)
+
+    # (4) gradient = directional derivative of lml (central difference along a fixed direction)
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal(d + 2)
+    u /= np.linalg.norm(u)
+    h = 1e-3 if f32 else 1e-5
+    lp = prob.lml_with_gradient(theta + h * u, want_grad=False)[0]
+    lm = prob.lml_with_gradient(theta - h * u, want_grad=False)[0]
+    fd = (lp - lm) / (2 * h)
+    assert abs(fd - grad @ u) <= (5e-2 if f32 else 1e-5) * max(1.0, np.abs(grad).max())
+
+    # (5) predict at training points: mean_i = y_i - s2 alpha_i exactly (K* = K - s2 I), variance in [0, c + 1e-5]
+    fk = gpr.FittedKernel.extend(X, y, theta)
+    idx = np.arange(0, n, max(1, n // 512))
+    mean, var, _ = fk.predict(X[idx])
+    np.testing.assert_allclose(mean.astype(np.float64), y[idx].astype(np.float64) - s2 * alpha[idx].astype(np.float64), rtol=0,
+                               atol=(1e-2 if f32 else 1e-8) * max(1.0, np.abs(y).max()))
+    assert np.all(var >= 0) and np.all(var <= c + 1e-4)
+    # (6) K^-1 is an inverse: K (K^-1 v) = v for the model's matrix, checked on its diagonal identity
+    #     var_i = 1e-5 + s2 - s2^2 Kinv_ii  (from k*_i = K_i - s2 e_i)
+    if n <= 4096:
+        _, kinv = fk.arrays()
+        want_var = 1e-5 + s2 - s2 * s2 * np.diag(kinv)[idx].astype(np.float64)
+        np.testing.assert_allclose(var.astype(np.float64), np.maximum(want_var, 0), rtol=0, atol=(2e-2 if f32 else 1e-8) * c)
+        v = rng.standard_normal(n)
+        back = K @ (kinv.astype(np.float64) @ v)
+        assert np.linalg.norm(back - v) <= (5e-2 if f32 else 1e-8) * np.linalg.norm(v) * 10
+
+
+def test_c3_eight_restart_fit_short():
+    # C3: 8 optimiser runs (1 + 7 restarts) on one GPU, shortened to 6 evaluations per run; the capture must be the
+    # arg-max over all 48 evaluations and the model must predict with that theta
+    w = synth.make_workload("C3")
+    starts = synth.restart_points("C3", w["lo"], w["hi"], 7)
+    fk = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, maxeval=6, trace=True)
+    tr = fk.trace
+    assert len(tr["lml"]) <= 48 and set(tr["run"].tolist()) == set(range(8))
+    assert fk.lml == tr["lml"].max()
+    mean, var, _ = fk.predict(w["X"][:16])
+    assert np.all(np.isfinite(mean)) and np.all(var >= 0)
