@@ -233,7 +233,7 @@ static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, st
   const int ntiles = (int)its.size();
   // resident workgroups per CU the kernel can reach (registers: 206 / 168 VGPRs for the 128- / 64-tile kernels)
   static const int occ_env = env_int("HBEGP_SCHED_OCC", 0);
-  const int occmax = occ_env > 0 ? occ_env : 2;  // measured at n=4096 (64-tiles): 2 per CU 49 TFLOP/s, 3 per CU 37, 1 per CU 40
+  const int occmax = occ_env > 0 ? occ_env : (tile == 128 ? 2 : 3);  // residency the kernels reach (VGPRs); pinned via the LDS request
   // Above ~2 tiles per resident slot the hardware dispatcher (tiles are listed deepest-first) balances better than a
   // static list (measured: LAUUM at n=4096, 2080 tiles: 50 vs 47 TFLOP/s); below it the static list wins (TRSM 29 -> 44).
   int nwg = 0;

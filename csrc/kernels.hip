@@ -325,9 +325,11 @@ static void launch_gemm_t(const GemmLaunch& gl, hipStream_t s) {
   // Static schedules assume exactly sched_nwg / 256 workgroups on every CU: pin that residency by asking for the matching
   // share of the 160 KiB LDS (otherwise the dispatcher may stack 3 workgroups on some CUs and 1 on others).
   if (g.sched_off && g.sched_nwg >= 256) {
-    const size_t share = ((size_t)163840 / (size_t)(g.sched_nwg / 256)) / 256 * 256;
+    const size_t share = ((size_t)163840 / (size_t)(g.sched_nwg / 256)) / 4096 * 4096;  // LDS is allocated in coarse granules
     if (share > lds) lds = share;
   }
+  static const size_t lds_min = getenv("HBEGP_GEMM_LDS_MIN") ? (size_t)atol(getenv("HBEGP_GEMM_LDS_MIN")) : 0;  // experiments: cap residency
+  if (lds_min > lds) lds = lds_min;
   hipLaunchKernelGGL((gemm_kernel<T, TILE>), dim3(total), dim3(256), lds, s, g);
 }
 

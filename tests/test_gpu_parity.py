@@ -155,3 +155,40 @@ def test_clamped_theta_and_bounds():
     # exp(ln(1e3)) is 1e3 only to an ulp, so compare to rounding rather than bitwise
     assert abs(got[0] - want[0]) <= 1e-10 * abs(want[0])
     np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (2, 3), (17, 1), (129, 2), (130, 64), (300, 5)])
+def test_edge_shapes(n, d):
+    # ragged sizes: single observation, n just above a 128 block, the maximum feature count (MAXD = 64)
+    rng = np.random.default_rng(n * 100 + d)
+    X = rng.random((n, d))
+    y = np.sin(X.sum(axis=1) * 3) + 0.05
+    theta = np.concatenate([[math.log(0.05), math.log(1.3)], np.log(0.4 + 0.1 * rng.random(d))])
+    s2, c, ell = split_theta(theta)
+    ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+    prob = gpr.Problem(X, y)
+    lml, grad = prob.lml_with_gradient(theta)
+    assert abs(lml - ref["lml"]) <= F64_TOL * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["grad"]).max()))
+    fk = gpr.FittedKernel.extend(X, y, theta)
+    Xs = rng.random((5, d))
+    mean, var, _ = fk.predict(Xs)
+    rmean, rvar, _ = O.predict(Xs, X, ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    np.testing.assert_allclose(mean, rmean, rtol=0, atol=F64_TOL * max(1.0, np.abs(rmean).max()))
+    np.testing.assert_allclose(var, rvar, rtol=0, atol=F64_TOL * c)
+    # empty candidate batch
+    m0, v0, _ = fk.predict(np.zeros((0, d)))
+    assert m0.shape == (0,) and v0.shape == (0,)
+
+
+def test_invalid_arguments_are_rejected():
+    X = np.random.default_rng(0).random((8, 2))
+    y = np.ones(8)
+    with pytest.raises(gpr.HbegpError) as e:
+        gpr.Problem(X, y, nu=2.0)  # matern_kernel.rs:79: unimplemented!
+    assert e.value.code == -1
+    with pytest.raises(gpr.HbegpError):
+        gpr.Problem(np.random.default_rng(0).random((8, 65)), y)  # d > MAXD
+    fk = gpr.FittedKernel.extend(X, y + np.arange(8) * 0.1, np.array([math.log(0.1), 0.0, 0.0, 0.0]))
+    with pytest.raises(AssertionError):
+        fk.predict(np.zeros((3, 5)))  # wrong feature count
