@@ -225,6 +225,16 @@ class SurrogateModelGPR:
         ei = np.array([expected_improvement(float(mi), float(math.sqrt(vi)), fmin_n) for mi, vi in zip(m, v)], dtype=self.dtype)
         return self.y_norm.project_location_from_normalized(m), ei
 
+    # Batched forms of the scalar trait methods (the acquisition loops call these once per generation
+    # instead of m single-point predicts, each of which reads all of K^-1).
+    def predict_confidence_bound_a(self, x, cb):
+        m, v = self._predict_norm(x)
+        return self.y_norm.project_location_from_normalized(m + np.sqrt(v) * self.dtype.type(cb))
+
+    def predict_mean_std_a(self, x):
+        m, v = self._predict_norm(x)
+        return self.y_norm.project_mean_from_normalized(m, v), self.y_norm.project_std_from_normalized(m, v)
+
     def predict_mean_ei(self, x, fmin):  # surrogate_model.rs:49-52
         mean, ei = self.predict_mean_ei_a(np.asarray(x, dtype=self.dtype)[None, :], fmin)
         return mean[0], ei[0]

@@ -106,3 +106,15 @@ def test_2d_sphere_with_noise_and_extend_and_ei():
     lo = model.predict_confidence_bound(np.array([0.1, 0.9]), -1.0)
     hi = model.predict_confidence_bound(np.array([0.1, 0.9]), 1.0)
     assert lo < hi
+
+
+def test_batched_forms_match_scalar_calls(density_model):
+    m = density_model.model
+    xs = np.linspace(0.05, 0.95, 7)[:, None]
+    cb_a = m.predict_confidence_bound_a(xs, 1.5)
+    cb_s = [m.predict_confidence_bound(x, 1.5) for x in xs]
+    np.testing.assert_allclose(cb_a, cb_s, rtol=1e-12, atol=1e-12)
+    mean_a, std_a = m.predict_mean_std_a(xs)
+    st = [m.predict_statistics(x) for x in xs]
+    np.testing.assert_allclose(mean_a, [s.mean() for s in st], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(std_a, [s.std() for s in st], rtol=1e-12, atol=1e-12)
