@@ -588,6 +588,21 @@ struct Problem : ProblemBase {
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
   }
 
+  // Kernel matrix + Cholesky/inverse-factor recursion only (no alpha, no K^-1): leaves X = L^-1 in the slot's W2.
+  // Used when a model is built: X of the captured theta is recomputed (bitwise the same arithmetic as in the evaluation).
+  int factor_only(size_t di, int si) {
+    Slot<T>& s = slots[di][si];
+    HIPCHECK(hipSetDevice(s.dev));
+    s.gemm_ord = 0;
+    HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
+    HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+    chol_inv(s, di, np / NB, nullptr);
+    HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+    HIPCHECK(hipStreamSynchronize(s.stream));
+    return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
+  }
+
   // Run one evaluation on (device index di, slot si) into ping-pong buffer `target`; blocks until the result is on the host.
   int run_eval(size_t di, int si, int target, bool want_grad, bool use_graph, double* lml, double* grad) {
     Slot<T>& s = slots[di][si];
@@ -711,6 +726,7 @@ struct hbegp_model {
   double lml = 0;
   std::vector<double> theta;  // clamped, log space
   void *X = nullptr, *alpha = nullptr, *Kinv = nullptr;  // device
+  void* Xinv = nullptr;  // L^-1 (lower), for the predictive variance as c + 1e-5 - |L^-1 k*|^2
   size_t kinv_bytes = 0;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
@@ -722,7 +738,7 @@ struct hbegp_model {
   ~hbegp_model() {
     (void)hipSetDevice(dev);
     if (stream) (void)hipStreamSynchronize(stream);
-    (void)hipFree(X); (void)hipFree(alpha); g_pool.put(dev, Kinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
+    (void)hipFree(X); (void)hipFree(alpha); g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
     (void)hipFree(Xs); (void)hipFree(Ks); (void)hipFree(Q); (void)hipFree(mean); (void)hipFree(var);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -739,10 +755,14 @@ static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double
   HIPCHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   HIPCHECK(hipMalloc(&m->X, sizeof(T) * (size_t)prob.n * prob.d));
   HIPCHECK(hipMalloc(&m->alpha, sizeof(T) * prob.np));
-  { bool fr; m->Kinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->kinv_bytes = sizeof(T) * nn; }
+  { bool fr; m->Kinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->Xinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->kinv_bytes = sizeof(T) * nn; }
   HIPCHECK(hipMalloc(&m->dP, sizeof(EvalParams)));
   HIPCHECK(hipMalloc(&m->dOut, sizeof(EvalOut)));
   const int b = s.best_idx < 0 ? s.last_target : s.best_idx;
+  // X = L^-1 at the model's theta (the evaluation slots only keep K^-1 and alpha of the captured evaluation)
+  theta_to_params(theta_clamped, nullptr, nullptr, prob.d, s.hP);
+  if (prob.factor_only(di, si) != HBEGP_OK) throw HipError{hipErrorUnknown, "factorisation at the captured theta failed", __LINE__};
+  HIPCHECK(hipMemcpyAsync(m->Xinv, s.W2, sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->X, prob.Xd[di], sizeof(T) * (size_t)prob.n * prob.d, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->alpha, s.alpha[b], sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->Kinv, s.Kinv[b], sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
@@ -778,17 +798,28 @@ static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, 
                   static_cast<T*>(m->Ks), s);
   launch_pred_mean<T>(static_cast<T*>(m->Ks), cnt, m->np, static_cast<T*>(m->alpha), static_cast<T*>(m->mean), s);
   if (var) {
-    // Q = Kstar * Kinv (Kinv symmetric: rows of Kinv are read along the contraction index)
+    static const bool kinv_form = env_int("HBEGP_PREDVAR_KINV", 0) != 0;
     GemmLaunch g{};
     g.nops = 1;
     g.info = &m->dOut->info;
     GemmOp& op = g.op[0];
-    op.A = m->Ks; op.B = m->Kinv; op.C = m->Q;
     op.lda = m->np; op.ldb = m->np; op.ldc = m->np;
     op.ci0 = 0; op.cj0 = 0; op.mi = mp / NB; op.nj = m->np / NB;
     op.k0 = 0; op.k1 = m->np / NB;
-    launch_gemm<T>(g, pick_tile(op.mi * op.nj), s);
-    launch_pred_var<T>(static_cast<T*>(m->Ks), static_cast<T*>(m->Q), cnt, m->np, m->dP, static_cast<T*>(m->var), m->dOut, s);
+    if (kinv_form) {
+      // the reference's literal formula (predict.rs:30-37): Q = Kstar * Kinv, var = c + 1e-5 - rowsum(Q o Kstar)
+      op.A = m->Ks; op.B = m->Kinv; op.C = m->Q;
+      launch_gemm<T>(g, pick_tile(op.mi * op.nj), s);
+      launch_pred_var<T>(static_cast<T*>(m->Ks), static_cast<T*>(m->Q), cnt, m->np, m->dP, static_cast<T*>(m->var), m->dOut, s);
+    } else {
+      // same quantity as k*^T K^-1 k* = |L^-1 k*|^2: Q = Kstar * X^T (X = L^-1 lower: k <= j, half the flops), then
+      // var = c + 1e-5 - rowsum(Q o Q).  A sum of squares has no cancellation inside the quadratic form, so the
+      // result is at least as close to the exact value as the K^-1 form.
+      op.A = m->Ks; op.B = m->Xinv; op.C = m->Q;
+      op.klim = 1; op.maskB = 1;
+      launch_gemm<T>(g, pick_tile(op.mi * op.nj), s);
+      launch_pred_var<T>(static_cast<T*>(m->Q), static_cast<T*>(m->Q), cnt, m->np, m->dP, static_cast<T*>(m->var), m->dOut, s);
+    }
   }
   HIPCHECK(hipMemcpyAsync(mean, m->mean, sizeof(T) * cnt, hipMemcpyDeviceToHost, s));
   if (var) HIPCHECK(hipMemcpyAsync(var, m->var, sizeof(T) * cnt, hipMemcpyDeviceToHost, s));

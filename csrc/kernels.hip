@@ -369,14 +369,16 @@ struct LeafGeom {
 //   (B) p < 4 only: wave 1 solves the rows beyond wave 0's window by substitution against L_pp (LDS broadcast reads)
 //       while waves 0,2,3 update the window rows of block column p+1;   (C) the remaining blocks of column p+1.
 // Tail: Y_7, block rows 6 and 7 of X.  fp64 MFMA for every 16x16x16 product.
-template <typename T>
-__global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __restrict__ W2, int ld, int blk,
-                                                   T* __restrict__ ldiag, int* info, int dbg) {
+// T = arithmetic type of the block (always double: the block is latency-bound, so f32 problems are factored in f64 too),
+// TIO = element type in HBM.
+template <typename T, typename TIO>
+__global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
+                                                   TIO* __restrict__ ldiag, int* info, int dbg) {
   using C = Cfg<T>;
   using L = LeafGeom<T>;
   using acc_t = typename C::acc_t;
-  using vec_t = typename C::vec_t;
-  constexpr int S = L::S, YS = L::YS, YB = L::YB, VEC = C::VEC;
+  using vec_t = typename Cfg<TIO>::vec_t;
+  constexpr int S = L::S, YS = L::YS, YB = L::YB, VEC = Cfg<TIO>::VEC;
   if (*info != 0) return;
 
   extern __shared__ __align__(16) char smem_raw[];
@@ -388,8 +390,8 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __r
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m16 = lane & 15, q4 = lane >> 4;
   const size_t g0 = (size_t)blk * NB * ld + (size_t)blk * NB;
-  T* Ablk = W1 + g0;
-  T* Xblk = W2 + g0;
+  TIO* Ablk = W1 + g0;
+  TIO* Xblk = W2 + g0;
 
   // load the block: all 16-byte chunks of a batch are issued before the first LDS store, so the loads overlap
   {
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __r
         const int c = t + 512 * (b0 + q);
         const int r = c / CPRW, cc = (c % CPRW) * VEC;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = buf[q][e];
+        for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = (T)buf[q][e];
       }
     }
   }
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __r
       const int row = C::crow(lane, r);
       const T v = -res[r];
       As[(j * 16 + m16) * S + i * 16 + row] = v;             // transposed copy for later products
-      Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16] = v;  // X[i,j]
+      Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16] = (TIO)v;  // X[i,j]
     }
   };
 
@@ -525,7 +527,7 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __r
           T dv = T(0);
 #pragma unroll
           for (int j = 0; j < 16; ++j) dv = (j == lane) ? a[j] : dv;
-          ldiag[blk * NB + p * 16 + lane] = dv;
+          ldiag[blk * NB + p * 16 + lane] = (TIO)dv;
           Rd[p * 16 + lane] = rinv_own;
         }
         if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
@@ -595,13 +597,13 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(T* __restrict__ W1, T* __r
   // diagonal sub-blocks of X
   for (int c = t; c < 8 * 256; c += 512) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
-    Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j] = Ys[pblk * YB + r * YS + j];
+    Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j] = (TIO)Ys[pblk * YB + r * YS + j];
   }
 }
 
 template <typename T>
 void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg) {
-  hipLaunchKernelGGL((leaf_kernel<T>), dim3(1), dim3(512), LeafGeom<T>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg);
+  hipLaunchKernelGGL((leaf_kernel<double, T>), dim3(1), dim3(512), LeafGeom<double>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg);
 }
 template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t, int);
 template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t, int);
@@ -1118,10 +1120,10 @@ static void init_gemm_attr() {
 void init_kernels() {
   init_gemm_attr<double, 128>(); init_gemm_attr<double, 64>(); init_gemm_attr<double, 32>();
   init_gemm_attr<float, 128>(); init_gemm_attr<float, 64>(); init_gemm_attr<float, 32>();
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<double, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LeafGeom<double>::LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LeafGeom<float>::LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<double, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LeafGeom<double>::LDS_BYTES);
 }
 
 __global__ void set_info_kernel(int* info, int value) { *info = value; }
