@@ -105,3 +105,22 @@ def test_sphere_1d_behaviour():
     truth = ((grid[:, 0] * 4 - 2) ** 2 - shift) / amp + 0.05
     std = np.sqrt(var)
     assert np.all(np.abs(mean - truth) <= 3 * std + 0.15)
+
+
+def test_runs_sharded_over_two_device_entries_give_the_same_model():
+    # The restart axis shards run r -> device index r mod G with a host-side arg-max.  One GPU box: list the
+    # same GPU twice, which drives the whole multi-device code path (per-device uploads, slots, schedules, global capture).
+    w = synth.make_workload("C2", n=300)
+    starts = synth.restart_points("C2", w["lo"], w["hi"], 3)
+    one = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, maxeval=25, trace=True)
+    ctx2 = gpr.Context(device_ids=[0, 0])
+    two = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, maxeval=25, trace=True, ctx=ctx2)
+    assert two.lml == one.lml and np.array_equal(two.theta, one.theta)
+    a1, k1 = one.arrays()
+    a2, k2 = two.arrays()
+    assert np.array_equal(a1, a2) and np.array_equal(k1, k2)
+    # every run's trajectory is independent of where it ran
+    for r in range(4):
+        np.testing.assert_array_equal(one.trace["lml"][one.trace["run"] == r], two.trace["lml"][two.trace["run"] == r])
+    two.release()
+    ctx2.close()
