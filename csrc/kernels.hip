@@ -68,7 +68,7 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 // =================================================================================================================
 // Tile GEMM
 // =================================================================================================================
-template <typename T, int TILE>
+template <typename T, int TILE, int KM = 0>
 struct GemmGeom {
   using C = Cfg<T>;
   // contraction depth per LDS stage: 128 bytes of k for the big tiles, 512 bytes for the 32-tiles (small, latency-bound
@@ -79,7 +79,7 @@ struct GemmGeom {
 #ifndef HBEGP_KMUL64
 #define HBEGP_KMUL64 1
 #endif
-  static constexpr int BKE = (TILE == 32 ? HBEGP_KMUL32 : (TILE == 64 ? HBEGP_KMUL64 : 1)) * C::BK;
+  static constexpr int BKE = (KM > 0 ? KM : (TILE == 32 ? HBEGP_KMUL32 : (TILE == 64 ? HBEGP_KMUL64 : 1))) * C::BK;
   static constexpr int SK = BKE + 2;          // LDS row stride, operand stored [outer][k]
   static constexpr int SM = TILE + 16;        // LDS row stride, operand stored [k][outer]
   static constexpr int LDSE = (TILE * SK > BKE * SM) ? TILE * SK : BKE * SM;  // elements per operand buffer
@@ -95,10 +95,10 @@ __device__ __forceinline__ int tri_row(int idx) {
   return r;
 }
 
-template <typename T, int TILE>
+template <typename T, int TILE, int KM = 0>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   using C = Cfg<T>;
-  using G = GemmGeom<T, TILE>;
+  using G = GemmGeom<T, TILE, KM>;
   using vec_t = typename C::vec_t;
   using acc_t = typename C::acc_t;
   constexpr int VEC = C::VEC, BK = G::BKE, SK = G::SK, SM = G::SM, NCH = G::NCH, TM = G::TM;
@@ -330,6 +330,13 @@ static void launch_gemm_t(const GemmLaunch& gl, hipStream_t s) {
   }
   static const size_t lds_min = getenv("HBEGP_GEMM_LDS_MIN") ? (size_t)atol(getenv("HBEGP_GEMM_LDS_MIN")) : 0;  // experiments: cap residency
   if (lds_min > lds) lds = lds_min;
+  // statically scheduled 64-tile launches run 2 workgroups per CU: there the deeper (BK x 2) stage variant fits the pinned
+  // LDS share and halves the number of barriers
+  static const bool deep = getenv("HBEGP_SCHED_DEEP") ? atoi(getenv("HBEGP_SCHED_DEEP")) != 0 : false;
+  if (TILE == 64 && deep && g.sched_off && g.sched_nwg == 512) {
+    hipLaunchKernelGGL((gemm_kernel<T, TILE, 2>), dim3(total), dim3(256), lds, s, g);
+    return;
+  }
   hipLaunchKernelGGL((gemm_kernel<T, TILE>), dim3(total), dim3(256), lds, s, g);
 }
 
@@ -1114,6 +1121,7 @@ template void launch_pred_var<float>(const float*, const float*, int, int, const
 // hbegp_ctx_create() for every device, before any stream capture.
 template <typename T, int TILE>
 static void init_gemm_attr() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             163840);
 }
