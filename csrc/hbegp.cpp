@@ -307,6 +307,15 @@ struct Problem : ProblemBase {
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
 
   Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_) {
+    try {
+      init(c, X, y, n_, d_, nu, n_slots_);
+    } catch (...) {
+      release();  // a constructor that throws never runs the destructor: give back what was allocated so far
+      throw;
+    }
+  }
+
+  void init(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_) {
     ctx = c; n = n_; d = d_; np = round_up(n_, NB); n_slots = n_slots_;
     nu2 = (int)std::lround(2 * nu);
     is_f32 = sizeof(T) == 4;
@@ -359,7 +368,9 @@ struct Problem : ProblemBase {
     }
     dry_ = false;
   }
-  ~Problem() override {
+  ~Problem() override { release(); }
+
+  void release() {
     for (size_t di = 0; di < slots.size(); ++di) {
       (void)hipSetDevice(ctx->devs[di]);
       for (auto& s : slots[di]) {
@@ -379,6 +390,10 @@ struct Problem : ProblemBase {
       if (di < scheds.size())
         for (auto& sc : scheds[di]) { (void)hipFree(sc.d_off); (void)hipFree(sc.d_items); }
     }
+    slots.clear();
+    scheds.clear();
+    Xd.clear();
+    yd.clear();
   }
 
   void gemm(Slot<T>& s, size_t di, GemmLaunch& g, PhaseTimer* tm, int kind) {
@@ -911,6 +926,9 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
       hip_fail(he);
       std::lock_guard<std::mutex> lk(err_mu);
       err = g_last_error;
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      err = std::string("worker thread: ") + e.what();
     }
   };
 
