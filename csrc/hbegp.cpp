@@ -242,7 +242,8 @@ static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, st
     for (int occ = occmax; occ >= 1; --occ)
       if (ntiles >= 2 * 256 * occ) { nwg = 256 * occ; break; }
   static const int sched_on = env_int("HBEGP_SCHED", 1);
-  if (!sched_on || nwg == 0) return false;
+  static const int sched_t32 = env_int("HBEGP_SCHED_T32", 1);
+  if (!sched_on || nwg == 0 || (tile == 32 && !sched_t32)) return false;
   std::stable_sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.w > b.w; });
   typedef std::pair<double, int> Load;  // (load, wg)
   std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
