@@ -48,6 +48,12 @@ def cpu_baseline(w, theta, Xs):
         t_pred = time.perf_counter() - t0
     n_evals = (1 + N_RESTARTS) * EVALS_PER_RUN
     fit_predict_s = n_evals * t_eval + t_pred
+    # best-effort variant beside it: the same port with every host core given to BLAS/LAPACK
+    import os as _os
+
+    t0 = time.perf_counter()
+    O.lml_with_gradient(w["X"], w["y"], s2, c, ell, 2.5)
+    t_eval_all = time.perf_counter() - t0
     return {
         "value": 1.0 / fit_predict_s,
         "unit": "fit+predict/s",
@@ -57,6 +63,8 @@ def cpu_baseline(w, theta, Xs):
                   f"n={w['n']} d={w['d']} f64, numpy + LAPACK dpotrf/dpotrs/dpotri, 1 thread",
         "eval_s": t_eval,
         "predict_s": t_pred,
+        "best_effort": {"cores": _os.cpu_count(), "eval_s": t_eval_all,
+                        "value": 1.0 / (n_evals * t_eval_all + t_pred), "note": "same port, all host cores for BLAS/LAPACK"},
     }, res
 
 
@@ -166,6 +174,13 @@ def main():
             },
             "roofline": roofline,
         }
+        # the same fit with the optimiser's own stopping rule (not timed above): evaluations it actually needs
+        t0 = time.perf_counter()
+        fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, nu=2.5, ctx=ctx, maxeval=EVALS_PER_RUN, trace=True)
+        t_conv = time.perf_counter() - t0
+        out["converged_fit"] = {"seconds": t_conv, "evaluations": int(len(fk.trace["lml"])), "lml": fk.lml,
+                                "note": "early-stopping fit (projected-gradient / progress tolerances of csrc/lbfgsb.hpp), same data and starts"}
+        fk.release()
         if world == 1 and not args.no_cpu_baseline:
             cb, ref = cpu_baseline(w, theta, Xs)
             out["cpu_baseline"] = cb

@@ -170,7 +170,7 @@ static int pick_tile(int tiles128) {
   // 128-tiles only when a launch has >= 600 of them (n >= 8192): measured n=8192 15.1 -> 13.7 ms/evaluation with them,
   // n=4096 LAUUM (528 tiles) 0.44 ms with 64-tiles vs 0.77 ms with 128-tiles
   if (tiles128 >= env_int("HBEGP_T128_MIN", 600)) return 128;
-  if (tiles128 >= env_int("HBEGP_T64_MIN", 100)) return 64;
+  if (tiles128 >= env_int("HBEGP_T64_MIN", 128)) return 64;  // h=1024 SYRK+U (100 tiles): 58 us with 32-tiles vs 83 us with 64-tiles
   return 32;
 }
 
@@ -1044,6 +1044,7 @@ int hbegp_ctx_create(int n_devices, const int* device_ids, hbegp_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       return fail(HBEGP_ENODEV, "device %d is %s; this library only carries gfx950 code", id, prop.gcnArchName);
     HIPCHECK(hipSetDevice(id));
+    if (env_int("HBEGP_SPIN", 0)) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
     init_kernels();
     ctx->devs.push_back(id);
   }
