@@ -124,3 +124,32 @@ def test_runs_sharded_over_two_device_entries_give_the_same_model():
         np.testing.assert_array_equal(one.trace["lml"][one.trace["run"] == r], two.trace["lml"][two.trace["run"] == r])
     two.release()
     ctx2.close()
+
+
+def test_fit_quality_matches_scipy_lbfgsb_on_the_oracle():
+    # The reference's optimiser (NLopt L-BFGS) is not available; scipy's L-BFGS-B on the CPU oracle's objective from the same
+    # start points is an independent stand-in: the GPU fit must reach (at least) the same maximum of the lml.
+    from scipy.optimize import minimize
+
+    w = synth.make_workload("C1")  # sphere d=2, n=64: BASELINE config 0
+    X, y = w["X"], w["y"]
+    starts = synth.restart_points("C1", w["lo"], w["hi"], 2)
+    fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts)
+    bounds = list(zip(w["lo"], w["hi"]))
+    lnb = [(math.log(a), math.log(b)) for a, b in bounds]
+
+    def obj(th):
+        f, g, _ = O.objective(th, X, y, 2.5, bounds)
+        return (1e30, np.zeros_like(th)) if not math.isfinite(f) else (f, g)
+
+    best = -math.inf
+    for x0 in [w["theta0"]] + list(starts):
+        r = minimize(obj, x0, jac=True, method="L-BFGS-B", bounds=lnb, options=dict(maxfun=150))
+        best = max(best, -r.fun)
+    assert fk.lml >= best - 1e-3 * max(1.0, abs(best)), (fk.lml, best)
+    # and the model really sits at a stationary point of the oracle's objective (projected gradient small)
+    f, g, _ = O.objective(fk.theta, X, y, 2.5, bounds)
+    at_lo = np.isclose(fk.theta, [b[0] for b in lnb]) & (g > 0)
+    at_hi = np.isclose(fk.theta, [b[1] for b in lnb]) & (g < 0)
+    pg = np.where(at_lo | at_hi, 0.0, g)
+    assert np.abs(pg).max() <= 1e-2 * max(1.0, abs(f))
