@@ -153,6 +153,9 @@ def main():
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
             "traffic": traffic,
             "traffic_unit": "bytes per launch (mean over the kernel's launches in one evaluation; profiles/r01_pmc_traffic.json)",
+            "launches_per_eval": ph[f"n_{big}"],
+            "gflop_per_launch": ph[f"{big}_gflop"] / max(ph[f"n_{big}"], 1.0),
+            "avg_launch_ms": ph[f"{big}_ms"] / max(ph[f"n_{big}"], 1.0),
             "algorithmic_gflop_per_eval": ph[f"{big}_gflop"],
             "kernel_ms_per_eval": ph[f"{big}_ms"],
             "whole_eval_ms": ph["eval_graph_ms"],

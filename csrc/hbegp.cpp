@@ -684,7 +684,7 @@ struct Problem : ProblemBase {
     float ms = 0;
     HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
     if (phase_ms) {
-      for (int i = 0; i < 16; ++i) phase_ms[i] = 0;
+      for (int i = 0; i < 20; ++i) phase_ms[i] = 0;
       phase_ms[6] = ms / reps;
       // eager pass with one event pair per launch
       const int treps = std::max(1, std::min(reps, 3));
@@ -719,6 +719,7 @@ struct Problem : ProblemBase {
             const int o = rec.tile == 128 ? 8 : (rec.tile == 64 ? 10 : 12);
             phase_ms[o] += v;
             phase_ms[o + 1] += rec.gflop / treps;
+            phase_ms[rec.tile == 128 ? 16 : (rec.tile == 64 ? 17 : 18)] += 1.0 / treps;  // launches per evaluation
           }
           (void)hipEventDestroy(rec.a);
           (void)hipEventDestroy(rec.b);

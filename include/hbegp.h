@@ -87,7 +87,9 @@ int hbegp_problem_kmat_f32(hbegp_problem* prob, int dev, int slot, const double*
 /* Timed evaluations for bench.py: runs `reps` evaluations at theta on (dev, slot) bracketed by hipEvents on the
  * slot's stream.  phase_ms (may be NULL) receives per-phase averages measured with events in eager mode:
  * [0] kmat, [1] chol+trtri GEMM launches (sum), [2] leaf (diag-block) launches (sum), [3] lauum GEMM,
- * [4] alpha/lml reductions, [5] gradtrace, [6] whole evaluation (graph replay), [7] number of GEMM launches/eval. */
+ * [4] alpha/lml reductions, [5] gradtrace, [6] whole evaluation (graph replay), [7] number of GEMM launches/eval,
+ * [8..13] (ms, algorithmic GFLOP) of the 128-, 64- and 32-tile GEMM launches, [14] eager evaluation, [15] leaf launches,
+ * [16..18] launches per evaluation of the 128-, 64-, 32-tile GEMM.  phase_ms must have room for 20 doubles. */
 int hbegp_problem_time_eval(hbegp_problem* prob, int dev, int slot, const double* theta, int reps,
                             double* phase_ms);
 
