@@ -139,14 +139,14 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            k = pmc[f"hbegp::gemm_kernel<double, {big[4:]}>"]
+            k = pmc.get(f"hbegp::gemm_kernel<double, {big[4:]}, 0>") or pmc[f"hbegp::gemm_kernel<double, {big[4:]}>"]
             if args.n is None:
                 traffic = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
         except Exception:
             traffic = None
         roofline = {
             "bound": "mfma",
-            "kernel": f"hbegp::gemm_kernel<double,{big[4:]}>",
+            "kernel": f"hbegp::gemm_kernel<double, {big[4:]}, 0>",
             "achieved": achieved,
             "peak": PEAK_FP64_MFMA_TFLOPS,
             "unit": "TFLOP/s",
