@@ -678,7 +678,10 @@ struct Problem : ProblemBase {
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
     HIPCHECK(hipEventRecord(e0, s.stream));
-    for (int r = 0; r < reps; ++r) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
+    for (int r = 0; r < reps; ++r) {
+      if (s.graph[0][1]) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
+      else enqueue_eval(s, (size_t)dev, 0, true, nullptr);  // HBEGP_NO_GRAPH=1
+    }
     HIPCHECK(hipEventRecord(e1, s.stream));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0;
