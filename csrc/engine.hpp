@@ -44,7 +44,7 @@ struct GemmOp {
   int c_lower;    // only tiles with global ti >= tj
   int k0, k1;     // contraction tile range [k0, k1)
   int klim;       // 0 none | 1: k <= tj | 2: k >= tj | 3: k <= ti | 4: k >= ti   (global tile coordinates)
-  int maskA, maskB;  // on storage-diagonal tiles treat elements with col > row as zero (lower-triangular operand)
+  int maskA, maskB;  // operand is lower triangular (its strict upper part is zero IN MEMORY; only used for flop accounting)
   int ntiles;     // output tiles of this op (set by the launcher)
   int reverse;    // walk the tile list backwards (set by the launcher)
   int alpha_neg;  // alpha = -1 instead of +1

@@ -342,9 +342,12 @@ struct Problem : ProblemBase {
           s.Kinv[b] = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fk));
           HIPCHECK(hipMalloc(&s.alpha[b], sizeof(T) * np));
         }
-        // Strict upper parts are never written by the engine but whole tiles of them are loaded (and masked, or
-        // multiplied by masked zeros) by the GEMM loader: they must hold finite numbers.
-        if (fresh2) HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
+        // W2 carries the triangular operand X = L^-1.  The GEMM loader does not mask: the strict upper triangle of W2 must
+        // BE zero (tiles on the diagonal are loaded whole).  Nothing in the engine writes there, so clearing the buffer
+        // once per slot is enough -- also when it is recycled from the pool (it may have held a full symmetric K^-1).
+        // W1's strict upper part is only ever multiplied by those zeros or ignored: it just has to be finite.
+        HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
+        (void)fresh2;
         if (fresh1) HIPCHECK(hipMemset(s.W1, 0, sizeof(T) * nn));
         HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));

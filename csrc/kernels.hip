@@ -184,34 +184,15 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   // two register sets: the loads of stage s+2 are in flight while stage s is computed and stage s+1 sits in LDS
   vec_t ra0[NCH], rb0[NCH], ra1[NCH], rb1[NCH];
 
-  auto load_stage = [&](int s, vec_t (&ra)[NCH], vec_t (&rb)[NCH]) {
+  // Triangular operands (X = L^-1 in W2 / the model's copy) need no masking: the strict upper triangle of those buffers
+  // is zero in memory (cleared when the slot is created; the diagonal blocks write explicit zeros above the diagonal).
+  auto load_stage = [&](vec_t (&ra)[NCH], vec_t (&rb)[NCH]) {
 #pragma unroll
     for (int q = 0; q < NCH; ++q) ra[q] = *reinterpret_cast<const vec_t*>(pA + q * a_qs);
 #pragma unroll
     for (int q = 0; q < NCH; ++q) rb[q] = *reinterpret_cast<const vec_t*>(pB + q * b_qs);
     pA += a_step;
     pB += b_step;
-    // lower-triangular operands: zero the storage elements with col > row (uniform branches; only slabs that reach
-    // above the diagonal pay for it)
-    const int kk = kbeg + s * BK;
-    if (op.maskA && (akm ? ti * TILE + TILE - 1 > kk : kk + BK - 1 > ti * TILE)) {
-#pragma unroll
-      for (int q = 0; q < NCH; ++q) {
-        const int gr = (akm ? kk : ti * TILE) + a_r0 + q * a_rpp, gc = (akm ? ti * TILE : kk) + a_c0;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (gc + e > gr) ra[q][e] = 0;
-      }
-    }
-    if (op.maskB && (bkm ? tj * TILE + TILE - 1 > kk : kk + BK - 1 > tj * TILE)) {
-#pragma unroll
-      for (int q = 0; q < NCH; ++q) {
-        const int gr = (bkm ? kk : tj * TILE) + b_r0 + q * b_rpp, gc = (bkm ? tj * TILE : kk) + b_c0;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          if (gc + e > gr) rb[q][e] = 0;
-      }
-    }
   };
   auto store_stage = [&](int buf, vec_t (&ra)[NCH], vec_t (&rb)[NCH]) {
 #pragma unroll
@@ -252,38 +233,71 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   if constexpr (TILE == 128) {
     // one register set (the 128-tile already holds 128 accumulator registers): loads of stage s+1 fly during stage s
     if (nstages > 0) {
-      load_stage(0, ra0, rb0);
+      load_stage(ra0, rb0);
       store_stage(0, ra0, rb0);
     }
     __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
+    int s = 0;
+    for (; s + 1 < nstages; ++s) {
       const int buf = s & 1;
-      if (s + 1 < nstages) load_stage(s + 1, ra0, rb0);
+      load_stage(ra0, rb0);
       compute_stage(buf);
-      if (s + 1 < nstages) store_stage(buf ^ 1, ra0, rb0);
+      __builtin_amdgcn_sched_barrier(0);
+      store_stage(buf ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+    if (s < nstages) {
+      compute_stage(s & 1);
       __syncthreads();
     }
   } else {
     // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
     if (nstages > 0) {
-      load_stage(0, ra0, rb0);
-      if (nstages > 1) load_stage(1, ra1, rb1);
+      load_stage(ra0, rb0);
+      if (nstages > 1) load_stage(ra1, rb1);
       store_stage(0, ra0, rb0);
     }
     __syncthreads();
     // steady state, unrolled by two so that the register sets are indexed statically:
     //   even s: loads(s+2) -> set 0 | compute LDS[0] | set 1 (stage s+1) -> LDS[1] | barrier
     //   odd  s: loads(s+2) -> set 1 | compute LDS[1] | set 0 (stage s+1) -> LDS[0] | barrier
-    for (int s = 0; s < nstages; s += 2) {
-      if (s + 2 < nstages) load_stage(s + 2, ra0, rb0);
+    // Two things keep the loads two stages ahead of their use in the generated code:
+    //  * the steady-state loop issues its loads unconditionally (the last stages are peeled off below): a load under an
+    //    `if` makes hipcc's wait-count insertion assume the no-load path and emit vmcnt(0) before the LDS stores, i.e.
+    //    wait for the loads issued a moment ago;
+    //  * the scheduling fences keep it from hoisting the LDS stores (and their vmcnt wait) above the stage's MFMAs.
+    // Left alone the exposed load latency costs 11 % (3 workgroups per CU) to 20 % (1 per CU) of the MFMA rate.
+    int s = 0;
+    for (; s + 3 < nstages; s += 2) {
+      load_stage(ra0, rb0);
       compute_stage(0);
-      if (s + 1 < nstages) store_stage(1, ra1, rb1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_stage(1, ra1, rb1);
       __syncthreads();
-      if (s + 1 >= nstages) break;
-      if (s + 3 < nstages) load_stage(s + 3, ra1, rb1);
+      load_stage(ra1, rb1);
       compute_stage(1);
-      if (s + 2 < nstages) store_stage(0, ra0, rb0);
+      __builtin_amdgcn_sched_barrier(0);
+      store_stage(0, ra0, rb0);
       __syncthreads();
+    }
+    // tail: 1..3 stages left (0 if the tile has none); LDS[0] holds stage s, register set 1 holds stage s+1
+    if (s < nstages) {
+      const int left = nstages - s;
+      if (left > 2) load_stage(ra0, rb0);
+      compute_stage(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (left > 1) store_stage(1, ra1, rb1);
+      __syncthreads();
+      if (left > 1) {
+        compute_stage(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (left > 2) store_stage(0, ra0, rb0);
+        __syncthreads();
+        if (left > 2) {
+          compute_stage(0);
+          __syncthreads();
+        }
+      }
     }
   }
 
