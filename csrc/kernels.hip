@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
     default: break;
   }
   // contraction range in elements, rounded outward to whole stages.  The extension stays inside the same 128-block:
-  // there a triangular operand is zero by the element-wise mask below and the other operand is finite.
+  // there a triangular operand is zero in memory (its strict upper triangle, see load_stage) and the other operand is finite.
   const int kbeg = (ka * TILE) / BK * BK, kend = (kb * TILE + BK - 1) / BK * BK;
   const int nstages = (kend - kbeg) / BK;
 
