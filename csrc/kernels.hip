@@ -214,19 +214,34 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   const int fa0 = (wm * (TILE / 2) + (lane & 15)) * soA + (lane >> 4) * skA;
   const int fb0 = 2 * G::LDSE + (wn * (TILE / 2) + (lane & 15)) * soB + (lane >> 4) * skB;
 
+  // Fragments are double-buffered in registers: the LDS reads of k-step k4+1 are issued before the MFMAs of k-step k4,
+  // otherwise every k-step exposes one LDS round trip (the MFMAs of a step are issued long before they finish, but the
+  // next reads cannot start until the last of them has been issued).
   auto compute_stage = [&](int buf) {
     const int ia = buf * G::LDSE + fa0, ib = buf * G::LDSE + fb0;
+    T af[2][TM], bf[2][TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[0][a] = lds[ia + a * 16 * soA];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) bf[0][b] = lds[ib + b * 16 * soB];
 #pragma unroll
     for (int k4 = 0; k4 < BK / 4; ++k4) {
-      T af[TM], bf[TM];
+      const int cur = k4 & 1, nxt = cur ^ 1;
+      if (k4 + 1 < BK / 4) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = lds[ia + a * 16 * soA + k4 * 4 * skA];
+        for (int a = 0; a < TM; ++a) af[nxt][a] = lds[ia + a * 16 * soA + (k4 + 1) * 4 * skA];
 #pragma unroll
-      for (int b = 0; b < TM; ++b) bf[b] = lds[ib + b * 16 * soB + k4 * 4 * skB];
+        for (int b = 0; b < TM; ++b) bf[nxt][b] = lds[ib + b * 16 * soB + (k4 + 1) * 4 * skB];
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = C::mfma(af[a], bf[b], acc[a][b]);
+        for (int b = 0; b < TM; ++b) acc[a][b] = C::mfma(af[cur][a], bf[cur][b], acc[a][b]);
+      // pin the order: [LDS reads of step k4+1] then [MFMAs of step k4] (hipcc otherwise sinks half of the reads below
+      // the MFMAs to save registers)
+      if (k4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);
+      if (k4 + 1 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
     }
   };
 
