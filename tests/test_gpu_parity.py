@@ -79,6 +79,31 @@ def test_against_oracle_mid_sizes_f64(cfg, n):
     np.testing.assert_allclose(var, rvar, rtol=0, atol=F64_TOL * c)
 
 
+def test_recycled_workspaces_keep_triangular_operands_clean():
+    """The tile GEMM does not mask triangular operands: the strict upper triangle of the L^-1 workspace has to be zero in
+    memory.  Workspaces come from a pool that also recycles full symmetric K^-1 buffers, so run several problems of one
+    size back to back (each leaves dirty buffers behind) and check every one against the oracle."""
+    n = 384
+    for rep, cfg in enumerate(["C3", "M", "C2", "C3"]):
+        w = synth.make_workload(cfg, n=n)
+        X, y, theta = w["X"], w["y"], w["theta"]
+        s2, c, ell = split_theta(theta)
+        ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+        fk = gpr.FittedKernel.extend(X, y, theta)          # leaves a model (K^-1, L^-1 copies) in the pool when dropped
+        prob = gpr.Problem(X, y, nu=2.5, n_slots=2)
+        for slot in (0, 1):
+            lml, grad = prob.lml_with_gradient(theta, slot=slot)
+            assert abs(lml - ref["lml"]) <= F64_TOL * max(1.0, abs(ref["lml"])), (rep, slot)
+            np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["grad"]).max()))
+            _, kinv, _ = prob.results(slot=slot)
+            np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=F64_TOL * np.abs(ref["k_inv"]).max())
+        Xs = synth.candidates(cfg, 64, w["d"])
+        _, var, _ = fk.predict(Xs)
+        _, rvar, _ = O.predict(Xs, X, ref["alpha"], ref["k_inv"], c, ell, 2.5)
+        np.testing.assert_allclose(var, rvar, rtol=0, atol=F64_TOL * c)
+        del prob, fk
+
+
 @pytest.mark.parametrize("nu", [0.5, 1.5, 2.5])
 def test_all_matern_orders(nu):
     w = synth.make_workload("C1")
