@@ -95,6 +95,9 @@ __device__ __forceinline__ int tri_row(int idx) {
   return r;
 }
 
+#ifndef HBEGP_XBAR
+#define HBEGP_XBAR 1  /* 64-tile: 64.7 -> 66.9 TFLOP/s at 3 workgroups per CU, 64.0 -> 66.5 at 2, 55.0 -> 61.5 at 1; 32-tile: 55.0 -> 52.9 */
+#endif
 #ifndef HBEGP_T128_TWOSETS
 #define HBEGP_T128_TWOSETS 0  /* two register sets spill at 128 accumulator registers: 52.9 vs 59.7 TFLOP/s */
 #endif
@@ -269,6 +272,65 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       __syncthreads();
     }
   } else {
+    if constexpr (TILE == 64 && HBEGP_XBAR) {
+    // Software pipelining across the stage barrier: the fragments of a whole stage live in registers, the LDS stores of
+    // the next stage are issued before the last-but-one k-step and the first fragments of the next stage are read
+    // right after the barrier, under the MFMAs of the last k-step -- so neither the store latency nor the first read
+    // latency sits between a barrier and an MFMA.
+    constexpr int NK = BK / 4;
+    T fa[NK][TM], fb[NK][TM];
+    auto read_frags = [&](int buf, int k4) {
+      const int ia = buf * G::LDSE + fa0 + k4 * 4 * skA, ib = buf * G::LDSE + fb0 + k4 * 4 * skB;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[k4][a] = lds[ia + a * 16 * soA];
+#pragma unroll
+      for (int b2 = 0; b2 < TM; ++b2) fb[k4][b2] = lds[ib + b2 * 16 * soB];
+    };
+    auto mfma_step = [&](int k4) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < TM; ++b2) acc[a][b2] = C::mfma(fa[k4][a], fb[k4][b2], acc[a][b2]);
+    };
+    // one stage; `cur` = LDS buffer of this stage.  On entry fa/fb[0] hold its first k-step.
+    auto stage = [&](int cur, bool do_load, vec_t (&la)[NCH], vec_t (&lb)[NCH], bool do_store, vec_t (&sa)[NCH],
+                     vec_t (&sb)[NCH], bool has_next) {
+      if (do_load) load_stage(la, lb);
+#pragma unroll
+      for (int k4 = 1; k4 < NK; ++k4) read_frags(cur, k4);
+#pragma unroll
+      for (int k4 = 0; k4 + 2 < NK; ++k4) mfma_step(k4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_store) store_stage(cur ^ 1, sa, sb);
+      if (NK >= 2) mfma_step(NK - 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      // fragments of k-step NK-1 are still needed: the next stage's first fragments go to slot 0
+      if (has_next) read_frags(cur ^ 1, 0);
+      mfma_step(NK - 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);  // reads first: their latency hides under the MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nstages > 0) {
+      load_stage(ra0, rb0);
+      if (nstages > 1) load_stage(ra1, rb1);
+      store_stage(0, ra0, rb0);
+      __syncthreads();
+      read_frags(0, 0);
+      int s = 0;
+      for (; s + 3 < nstages; s += 2) {
+        stage(0, true, ra0, rb0, true, ra1, rb1, true);
+        stage(1, true, ra1, rb1, true, ra0, rb0, true);
+      }
+      const int left = nstages - s;  // 1..3
+      stage(0, left > 2, ra0, rb0, left > 1, ra1, rb1, left > 1);
+      if (left > 1) stage(1, false, ra1, rb1, left > 2, ra0, rb0, left > 2);
+      if (left > 2) stage(0, false, ra0, rb0, false, ra1, rb1, false);
+      __syncthreads();  // the next tile of this workgroup overwrites LDS
+    }
+    } else {
     // prologue: stage 0 -> LDS buffer 0, stage 1 -> register set 1
     if (nstages > 0) {
       load_stage(ra0, rb0);
@@ -316,6 +378,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
           __syncthreads();
         }
       }
+    }
     }
   }
 
