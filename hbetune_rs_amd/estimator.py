@@ -240,6 +240,43 @@ class SurrogateModelGPR:
         return mean[0], ei[0]
 
 
+def find_best_candidate_by_ei(candidates, model, fmin):
+    """acquisition.rs:177-202 over a feature array: index, mean and EI of the candidate with maximal EI.
+    One batched predict instead of a scalar `predict_mean_ei` per candidate.  Ties go to the LAST maximal element, as
+    Rust's `Iterator::max_by` does; a NaN EI raises like the reference's panic."""
+    means, eis = model.predict_mean_ei_a(np.asarray(candidates), fmin)
+    return _pick(means, eis, _argmax_last(eis[None, :])[0])
+
+
+def _argmax_last(eis2d):
+    eis2d = np.asarray(eis2d)
+    if np.isnan(eis2d).any():
+        raise ValueError("EI should be comparable")  # acquisition.rs:193-195
+    # index of the last maximum of every row
+    rev = eis2d[:, ::-1]
+    return eis2d.shape[1] - 1 - np.argmax(rev, axis=1)
+
+
+def _pick(means, eis, i):
+    return int(i), means[i], eis[i]
+
+
+def acquire_by_mutation(candidates, model, fmin):
+    """`MutationAcquisition::acquire` (acquisition.rs:86-116) after candidate generation: `candidates` is
+    [n_parents, breadth, n_features] (the caller's `generate_nearby_samples`, projected into features); returns, per
+    parent, the index of its best candidate and that candidate's mean and EI.  The whole generation is ONE batched
+    predict instead of n_parents*breadth single-point predicts."""
+    c = np.asarray(candidates)
+    if c.ndim != 3:
+        raise ValueError("candidates must be [n_parents, breadth, n_features]")
+    npar, breadth, nf = c.shape
+    means, eis = model.predict_mean_ei_a(c.reshape(npar * breadth, nf), fmin)
+    means, eis = means.reshape(npar, breadth), eis.reshape(npar, breadth)
+    idx = _argmax_last(eis)
+    rows = np.arange(npar)
+    return idx, means[rows, idx], eis[rows, idx]
+
+
 class EstimatorGPR:
     """gpr.rs:215-400: defaults, builders, estimate(), extend()."""
 

@@ -60,3 +60,42 @@ def test_bounds_error_like_reference():
     est = E.EstimatorGPR.new(1).noise_bounds(2.0, 3.0)  # default start 1.0 is outside -> Error::NoiseBounds (gpr.rs:411-412)
     with pytest.raises(E.BoundsError):
         est._theta_and_bounds(None, np.array([0.1, 1.0]))
+
+
+class _FakeModel:
+    """Stands in for SurrogateModelGPR: EI is a fixed function of the first feature (no GPU needed)."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def predict_mean_ei_a(self, x, fmin):
+        self.calls += 1
+        x = np.asarray(x)
+        ei = np.round(np.sin(7.0 * x[:, 0]) ** 2, 1)  # coarse values -> plenty of ties
+        return x.sum(axis=1), ei
+
+
+def test_batched_acquisition_matches_scalar_loop_and_rust_tie_rule():
+    rng = np.random.default_rng(3)
+    cand = rng.random((6, 25, 3))
+    model = _FakeModel()
+    idx, mean, ei = E.acquire_by_mutation(cand, model, fmin=0.0)
+    assert model.calls == 1  # the whole generation in one predict
+    for p in range(6):
+        # acquisition.rs:177-202 with Iterator::max_by: the LAST of several maximal elements wins
+        m_p, e_p = _FakeModel().predict_mean_ei_a(cand[p], 0.0)
+        best = max(range(25), key=lambda i: (e_p[i], i))
+        assert idx[p] == best and ei[p] == e_p[best] and mean[p] == m_p[best]
+        i1, m1, e1 = E.find_best_candidate_by_ei(cand[p], _FakeModel(), 0.0)
+        assert (i1, m1, e1) == (best, m_p[best], e_p[best])
+
+
+def test_batched_acquisition_rejects_nan_ei():
+    class Bad(_FakeModel):
+        def predict_mean_ei_a(self, x, fmin):
+            m, e = super().predict_mean_ei_a(x, fmin)
+            e[0] = np.nan
+            return m, e
+
+    with pytest.raises(ValueError):
+        E.find_best_candidate_by_ei(np.zeros((4, 3)), Bad(), 0.0)

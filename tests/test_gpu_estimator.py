@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+from hbetune_rs_amd import estimator as E
 from hbetune_rs_amd.estimator import EstimatorGPR, RNG
 
 pytestmark = pytest.mark.gpu
@@ -118,3 +119,20 @@ def test_batched_forms_match_scalar_calls(density_model):
     st = [m.predict_statistics(x) for x in xs]
     np.testing.assert_allclose(mean_a, [s.mean() for s in st], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(std_a, [s.std() for s in st], rtol=1e-12, atol=1e-12)
+
+
+def test_batched_acquisition_matches_the_reference_scalar_loop(density_model):
+    """acquisition.rs:86-116, 177-202: per parent, the candidate with maximal EI -- one batched predict for the whole
+    generation against the reference's loop of single-point `predict_mean_ei` calls."""
+    m = density_model.model
+    rng = np.random.default_rng(11)
+    cand = rng.random((5, 20, 1))
+    fmin = 0.3
+    idx, mean, ei = E.acquire_by_mutation(cand, m, fmin)
+    for p in range(5):
+        scalar = [m.predict_mean_ei(c, fmin) for c in cand[p]]
+        e = np.array([s[1] for s in scalar])
+        best = max(range(len(e)), key=lambda i: (e[i], i))  # Iterator::max_by keeps the last maximum
+        assert idx[p] == best
+        np.testing.assert_allclose(mean[p], scalar[best][0], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(ei[p], scalar[best][1], rtol=1e-8, atol=1e-12)
