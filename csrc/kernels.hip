@@ -425,13 +425,6 @@ static void launch_gemm_t(const GemmLaunch& gl, hipStream_t s) {
   }
   static const size_t lds_min = getenv("HBEGP_GEMM_LDS_MIN") ? (size_t)atol(getenv("HBEGP_GEMM_LDS_MIN")) : 0;  // experiments: cap residency
   if (lds_min > lds) lds = lds_min;
-  // statically scheduled 64-tile launches run 2 workgroups per CU: there the deeper (BK x 2) stage variant fits the pinned
-  // LDS share and halves the number of barriers
-  static const bool deep = getenv("HBEGP_SCHED_DEEP") ? atoi(getenv("HBEGP_SCHED_DEEP")) != 0 : false;
-  if (TILE == 64 && deep && g.sched_off && g.sched_nwg == 512) {
-    hipLaunchKernelGGL((gemm_kernel<T, TILE, 2>), dim3(total), dim3(256), lds, s, g);
-    return;
-  }
   hipLaunchKernelGGL((gemm_kernel<T, TILE>), dim3(total), dim3(256), lds, s, g);
 }
 
@@ -1216,7 +1209,6 @@ template void launch_pred_var<float>(const float*, const float*, int, int, const
 // hbegp_ctx_create() for every device, before any stream capture.
 template <typename T, int TILE>
 static void init_gemm_attr() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             163840);
 }
