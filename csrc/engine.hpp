@@ -100,4 +100,8 @@ void launch_pred_var(const T* Ks, const T* Q, int m, int np, const EvalParams* P
 
 void launch_set_info(int* info, int value, hipStream_t s);
 
+// *flag |= 1 when the two device arrays differ anywhere in [0, count)
+template <typename T>
+void launch_prefix_differs(const T* a, const T* b, size_t count, int* flag, hipStream_t s);
+
 }  // namespace hbegp

@@ -79,6 +79,7 @@ struct hbegp_ctx {
 // milliseconds per fit; the caller fits one model per generation with slowly growing n, so blocks are recycled by
 // exact size.  Recycled blocks hold finite numbers from their previous life, which is all the engine requires of
 // never-written regions (strict upper triangles).
+#include <chrono>
 #include <map>
 struct DevPool {
   std::mutex mu;
@@ -306,9 +307,12 @@ struct Problem : ProblemBase {
   std::vector<std::vector<Slot<T>>> slots;  // [device][slot]
   std::vector<std::vector<Sched>> scheds;   // [device][gemm launch ordinal]
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
+  bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
 
-  Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_) {
+  // single_shot: the problem runs one evaluation (extend): skip the static schedule tables, every GEMM launch is ad hoc
+  Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_, bool single_shot = false) {
     try {
+      adhoc_ = single_shot;
       init(c, X, y, n_, d_, nu, n_slots_);
     } catch (...) {
       release();  // a constructor that throws never runs the destructor: give back what was allocated so far
@@ -365,6 +369,7 @@ struct Problem : ProblemBase {
     }
     // build the static GEMM schedules (per device; shared by its slots) by walking one evaluation without launching
     scheds.resize(c->devs.size());
+    if (adhoc_) return;
     dry_ = true;
     for (size_t di = 0; di < c->devs.size(); ++di) {
       HIPCHECK(hipSetDevice(c->devs[di]));
@@ -426,6 +431,13 @@ struct Problem : ProblemBase {
       scheds[di][ord] = sc;
       return;
     }
+    if (adhoc_) {  // launch sequences other than the evaluation's (incremental extend): hardware dispatch, no table
+      g.sched_off = nullptr; g.sched_items = nullptr; g.sched_nwg = 0;
+      int tiles = 0;
+      for (int i = 0; i < g.nops; ++i) tiles += g.op[i].c_lower ? g.op[i].mi * (g.op[i].mi + 1) / 2 : g.op[i].mi * g.op[i].nj;
+      launch_gemm<T>(g, pick_tile(tiles), stream);
+      return;
+    }
     const Sched& sc = scheds[di][ord];
     g.sched_off = sc.nwg ? sc.d_off : nullptr;
     g.sched_items = sc.nwg ? sc.d_items : nullptr;
@@ -448,8 +460,13 @@ struct Problem : ProblemBase {
       if (tm) tm->end();
       return;
     }
-    const int mid = lo + (hi - lo) / 2;
-    chol_inv_rec(s, di, lo, mid, tm);
+    chol_inv_split(s, di, lo, lo + (hi - lo) / 2, hi, tm, false);
+  }
+
+  // One node of the recursion with an explicit split point.  left_done: X (and L's diagonal) of [lo, mid) are already in
+  // place (incremental extend), only the border and the right part are computed.
+  void chol_inv_split(Slot<T>& s, size_t di, int lo, int mid, int hi, PhaseTimer* tm, bool left_done) {
+    if (!left_done) chol_inv_rec(s, di, lo, mid, tm);
     GemmOp base{};
     base.lda = base.ldb = base.ldc = np;
     {
@@ -622,6 +639,75 @@ struct Problem : ProblemBase {
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
   }
 
+  // Incremental extend (the reference refactorises from scratch, fit.rs:33-68): the prior model was
+  // built at the same theta on a prefix of these rows, so the leading q0 = floor(n_prior / 128) diagonal blocks of L,
+  // X = L^-1 and the matching block of K^-1 are reused:
+  //   [X11 0; X21 X22]:  T = A21 X11^T,  A22 -= T T^T,  U = T X11,  chol_inv(A22),  X21 = -X22 U          O(n^2 k)
+  //   K^-1 = [K11^-1 + X21^T X21, .; X22^T X21, X22^T X22]                                                   O(n^2 k)
+  // Results go to ping-pong buffer 0 of slot (di, si).  Returns HBEGP_EINVAL when nothing can be reused.
+  int extend_from(size_t di, int si, const T* pX, const T* pXinv, const T* pKinv, const T* pldiag, int pn, int pnp) {
+    Slot<T>& s = slots[di][si];
+    HIPCHECK(hipSetDevice(s.dev));
+    const int nb = np / NB, q0 = std::min(pn / NB, nb - 1);
+    if (q0 < 1 || pn > n) return HBEGP_EINVAL;
+    const int* info = &s.dOut->info;
+    HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
+    HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+    // same leading rows?  (only the kept blocks matter, compare the whole prior prefix anyway)
+    launch_prefix_differs<T>(Xd[di], pX, (size_t)pn * d, &s.dOut->n_warn, s.stream);
+    HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+    HIPCHECK(hipStreamSynchronize(s.stream));
+    if (s.hOut->n_warn != 0) {
+      HIPCHECK(hipMemsetAsync(&s.dOut->n_warn, 0, sizeof(int), s.stream));
+      return HBEGP_EINVAL;
+    }
+    const size_t w = (size_t)q0 * NB;
+    HIPCHECK(hipMemcpy2DAsync(s.W2, sizeof(T) * np, pXinv, sizeof(T) * pnp, sizeof(T) * w, w, hipMemcpyDeviceToDevice, s.stream));
+    HIPCHECK(hipMemcpy2DAsync(s.Kinv[0], sizeof(T) * np, pKinv, sizeof(T) * pnp, sizeof(T) * w, w, hipMemcpyDeviceToDevice, s.stream));
+    HIPCHECK(hipMemcpyAsync(s.ldiag, pldiag, sizeof(T) * w, hipMemcpyDeviceToDevice, s.stream));
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+    const bool was_adhoc = adhoc_;
+    adhoc_ = true;
+    try {
+      chol_inv_split(s, di, 0, q0, nb, nullptr, true);
+      launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[0], s.dOut, info, s.stream);
+      if (pnp / NB > q0) {
+        // the prior's K^-1 also holds X^T X contributions of its own trailing (partial) block, which is being replaced:
+        // take them out of the kept block first
+        GemmLaunch gf{};
+        gf.nops = 1;
+        GemmOp& fix = gf.op[0];
+        fix.A = pXinv; fix.B = pXinv; fix.C = s.Kinv[0];
+        fix.lda = fix.ldb = pnp; fix.ldc = np;
+        fix.a_kmajor = 1; fix.b_kmajor = 1;
+        fix.mi = fix.nj = q0; fix.c_lower = 1;
+        fix.k0 = q0; fix.k1 = pnp / NB; fix.alpha_neg = 1; fix.beta_one = 1;
+        gemm(s, di, gf, nullptr, PhaseTimer::LAUUM);
+      }
+      GemmLaunch g{};
+      GemmOp base{};
+      base.lda = base.ldb = base.ldc = np;
+      base.A = s.W2; base.B = s.W2; base.C = s.Kinv[0];
+      base.a_kmajor = 1; base.b_kmajor = 1;
+      base.k0 = q0; base.k1 = nb; base.maskA = 1; base.maskB = 1;
+      GemmOp& keep = g.op[g.nops++];   // kept block: += X21^T X21
+      keep = base; keep.mi = keep.nj = q0; keep.c_lower = 1; keep.beta_one = 1;
+      GemmOp& rect = g.op[g.nops++];   // new rows x kept columns: X22^T X21 (k >= i)
+      rect = base; rect.ci0 = q0; rect.mi = nb - q0; rect.nj = q0; rect.klim = 4;
+      GemmOp& tri = g.op[g.nops++];    // new rows x new columns (lower)
+      tri = base; tri.ci0 = tri.cj0 = q0; tri.mi = tri.nj = nb - q0; tri.c_lower = 1; tri.klim = 4;
+      gemm(s, di, g, nullptr, PhaseTimer::LAUUM);
+    } catch (...) {
+      adhoc_ = was_adhoc;
+      throw;
+    }
+    adhoc_ = was_adhoc;
+    HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+    HIPCHECK(hipStreamSynchronize(s.stream));
+    s.last_target = 0;
+    return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
+  }
+
   // Run one evaluation on (device index di, slot si) into ping-pong buffer `target`; blocks until the result is on the host.
   int run_eval(size_t di, int si, int target, bool want_grad, bool use_graph, double* lml, double* grad) {
     Slot<T>& s = slots[di][si];
@@ -750,6 +836,7 @@ struct hbegp_model {
   std::vector<double> theta;  // clamped, log space
   void *X = nullptr, *alpha = nullptr, *Kinv = nullptr;  // device
   void* Xinv = nullptr;  // L^-1 (lower), for the predictive variance as c + 1e-5 - |L^-1 k*|^2
+  void* ldiag = nullptr; // diag(L), np entries (incremental extend needs the log-determinant of the kept part)
   size_t kinv_bytes = 0;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
@@ -761,14 +848,15 @@ struct hbegp_model {
   ~hbegp_model() {
     (void)hipSetDevice(dev);
     if (stream) (void)hipStreamSynchronize(stream);
-    (void)hipFree(X); (void)hipFree(alpha); g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
+    (void)hipFree(X); (void)hipFree(alpha); (void)hipFree(ldiag); g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
     (void)hipFree(Xs); (void)hipFree(Ks); (void)hipFree(Q); (void)hipFree(mean); (void)hipFree(var);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
 
 template <typename T>
-static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double* theta_clamped, double lml) {
+static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double* theta_clamped, double lml,
+                               bool w2_current = false) {
   Slot<T>& s = prob.slots[di][si];
   HIPCHECK(hipSetDevice(s.dev));
   std::unique_ptr<hbegp_model> m(new hbegp_model());
@@ -783,8 +871,13 @@ static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double
   HIPCHECK(hipMalloc(&m->dOut, sizeof(EvalOut)));
   const int b = s.best_idx < 0 ? s.last_target : s.best_idx;
   // X = L^-1 at the model's theta (the evaluation slots only keep K^-1 and alpha of the captured evaluation)
-  theta_to_params(theta_clamped, nullptr, nullptr, prob.d, s.hP);
-  if (prob.factor_only(di, si) != HBEGP_OK) throw HipError{hipErrorUnknown, "factorisation at the captured theta failed", __LINE__};
+  // (w2_current: the slot's last evaluation WAS at this theta -- extend -- so W2 and ldiag already hold them)
+  if (!w2_current) {
+    theta_to_params(theta_clamped, nullptr, nullptr, prob.d, s.hP);
+    if (prob.factor_only(di, si) != HBEGP_OK) throw HipError{hipErrorUnknown, "factorisation at the captured theta failed", __LINE__};
+  }
+  HIPCHECK(hipMalloc(&m->ldiag, sizeof(T) * prob.np));
+  HIPCHECK(hipMemcpyAsync(m->ldiag, s.ldiag, sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->Xinv, s.W2, sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->X, prob.Xd[di], sizeof(T) * (size_t)prob.n * prob.d, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->alpha, s.alpha[b], sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
@@ -982,7 +1075,7 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
                      const double* hi, hbegp_model** model_out) {
   hbegp_ctx one;
   one.devs = {ctx->devs[0]};
-  Problem<T> prob(&one, X, y, n, d, nu, 1);
+  Problem<T> prob(&one, X, y, n, d, nu, 1, env_int("HBEGP_EXTEND_SCHED", 0) == 0);
   const int p = d + 2;
   Slot<T>& s = prob.slots[0][0];
   theta_to_params(theta, lo, hi, d, s.hP);
@@ -998,7 +1091,46 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
       if (hi[i] < v) v = hi[i];
       th[i] = std::log(v);
     }
-  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml);
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml, true);
+  return HBEGP_OK;
+}
+
+// extend with a prior model fitted on a prefix of the rows (minimize.rs:629-644 appends the validation samples to the
+// data the last model was built from): same theta, incremental factorisation; falls back to the full path when the
+// prefix does not match or is shorter than one 128-block.
+template <typename T>
+static int do_extend_from(hbegp_ctx* ctx, hbegp_model* prior, const T* X, const T* y, int n, hbegp_model** model_out,
+                          int* incremental) {
+  if (incremental) *incremental = 0;
+  const int d = prior->d, p = d + 2;
+  const double nu = prior->nu2 / 2.0;
+  if (prior->dev != ctx->devs[0] || n < prior->n || prior->n < NB || !prior->ldiag)
+    return do_extend<T>(ctx, X, y, n, d, nu, prior->theta.data(), nullptr, nullptr, model_out);
+  hbegp_ctx one;
+  one.devs = {ctx->devs[0]};
+  static const int timing = env_int("HBEGP_TIMING", 0);
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  Problem<T> prob(&one, X, y, n, d, nu, 1, true);
+  const auto t1 = now();
+  Slot<T>& s = prob.slots[0][0];
+  theta_to_params(prior->theta.data(), nullptr, nullptr, d, s.hP);
+  int st;
+  {
+    std::lock_guard<std::mutex> lock(prior->mu);
+    st = prob.extend_from(0, 0, static_cast<const T*>(prior->X), static_cast<const T*>(prior->Xinv),
+                          static_cast<const T*>(prior->Kinv), static_cast<const T*>(prior->ldiag), prior->n, prior->np);
+  }
+  if (st == HBEGP_EINVAL) return do_extend<T>(ctx, X, y, n, d, nu, prior->theta.data(), nullptr, nullptr, model_out);
+  if (st != HBEGP_OK) return fail(HBEGP_NOT_PD, "Kernel matrix must be invertible.");  // fit.rs:55
+  s.best_idx = 0;
+  if (incremental) *incremental = 1;
+  (void)p;
+  const auto t2 = now();
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, prior->theta.data(), s.hOut->lml, true);
+  const auto t3 = now();
+  if (timing) fprintf(stderr, "extend_from: problem %.3f ms, factor %.3f ms, model %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
   return HBEGP_OK;
 }
 
@@ -1199,6 +1331,25 @@ int hbegp_extend_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int 
   if (!theta) return fail(HBEGP_EINVAL, "theta is NULL");
   GUARD_BEGIN
   return do_extend<float>(ctx, X, y, n, d, nu, theta, lo, hi, model);
+  GUARD_END
+}
+
+int hbegp_extend_from_f64(hbegp_ctx* ctx, hbegp_model* prior, const double* X, const double* y, int n, hbegp_model** model,
+                          int* incremental) {
+  if (!ctx || !prior || !X || !y) return fail(HBEGP_EINVAL, "ctx/prior/X/y is NULL");
+  if (prior->is_f32) return fail(HBEGP_EINVAL, "prior model holds f32 data");
+  if (n < 1) return fail(HBEGP_EINVAL, "n must be >= 1 (got %d)", n);
+  GUARD_BEGIN
+  return do_extend_from<double>(ctx, prior, X, y, n, model, incremental);
+  GUARD_END
+}
+int hbegp_extend_from_f32(hbegp_ctx* ctx, hbegp_model* prior, const float* X, const float* y, int n, hbegp_model** model,
+                          int* incremental) {
+  if (!ctx || !prior || !X || !y) return fail(HBEGP_EINVAL, "ctx/prior/X/y is NULL");
+  if (!prior->is_f32) return fail(HBEGP_EINVAL, "prior model holds f64 data");
+  if (n < 1) return fail(HBEGP_EINVAL, "n must be >= 1 (got %d)", n);
+  GUARD_BEGIN
+  return do_extend_from<float>(ctx, prior, X, y, n, model, incremental);
   GUARD_END
 }
 

@@ -14,6 +14,7 @@
 // (A frag: lane l holds A[l&15][l>>4]; B frag: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4)+4r for f64,
 //  4*(l>>4)+r for f32).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1096,6 +1097,23 @@ void launch_symmetrize(T* A, int np, hipStream_t s) {
 }
 template void launch_symmetrize<double>(double*, int, hipStream_t);
 template void launch_symmetrize<float>(float*, int, hipStream_t);
+
+// flag |= 1 when a[0..count) and b[0..count) differ anywhere (bitwise comparison of the stored values)
+template <typename T>
+__global__ void __launch_bounds__(256) prefix_differs_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t count,
+                                                             int* __restrict__ flag) {
+  bool diff = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) diff |= !(a[i] == b[i]);
+  if (diff) atomicOr(flag, 1);
+}
+template <typename T>
+void launch_prefix_differs(const T* a, const T* b, size_t count, int* flag, hipStream_t s) {
+  if (count == 0) return;
+  const int blocks = (int)std::min<size_t>(1024, (count + 255) / 256);
+  hipLaunchKernelGGL((prefix_differs_kernel<T>), dim3(blocks), dim3(256), 0, s, a, b, count, flag);
+}
+template void launch_prefix_differs<double>(const double*, const double*, size_t, int*, hipStream_t);
+template void launch_prefix_differs<float>(const float*, const float*, size_t, int*, hipStream_t);
 
 // =================================================================================================================
 // predict (predict.rs:7-52)

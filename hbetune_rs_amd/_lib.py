@@ -64,6 +64,8 @@ SIGNATURES = {
                                 C.POINTER(FitOptions), _dp, _dp, C.POINTER(_vp)]),
     "hbegp_extend_f64": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, C.POINTER(_vp)]),
     "hbegp_extend_f32": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, C.POINTER(_vp)]),
+    "hbegp_extend_from_f64": (C.c_int, [_vp, _vp, _dp, _dp, C.c_int, C.POINTER(_vp), _ip]),
+    "hbegp_extend_from_f32": (C.c_int, [_vp, _vp, _fp, _fp, C.c_int, C.POINTER(_vp), _ip]),
     "hbegp_predict_f64": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp, _ip]),
     "hbegp_predict_f32": (C.c_int, [_vp, _fp, C.c_int, _fp, _fp, _ip]),
     "hbegp_model_info": (C.c_int, [_vp, _ip, _ip, _ip, _dp, _dp]),

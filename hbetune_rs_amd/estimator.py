@@ -359,5 +359,10 @@ class EstimatorGPR:
         y_train, y_norm = YNormalize.new_project_into_normalized(y, self._y_projection, self._known_optimum)
         lo = np.array([prior.noise_bounds[0], prior.amplitude_bounds[0]] + [b[0] for b in prior.length_scale_bounds])
         hi = np.array([prior.noise_bounds[1], prior.amplitude_bounds[1]] + [b[1] for b in prior.length_scale_bounds])
-        fitted = gpr.FittedKernel.extend(x, y_train.astype(x.dtype), prior.fitted.theta, lo, hi, nu=self._matern_nu, ctx=self.ctx)
+        if prior.fitted.nu == self._matern_nu and prior.fitted.dtype == x.dtype:
+            # the caller appends its validation samples to the rows the prior was built on (minimize.rs:629-644): the engine
+            # reuses the prior's factorisation for the unchanged leading rows (falls back by itself when they differ)
+            fitted = prior.fitted.extend_with(x, y_train.astype(x.dtype), ctx=self.ctx)
+        else:
+            fitted = gpr.FittedKernel.extend(x, y_train.astype(x.dtype), prior.fitted.theta, lo, hi, nu=self._matern_nu, ctx=self.ctx)
         return SurrogateModelGPR(fitted, prior.noise_bounds, prior.amplitude_bounds, prior.length_scale_bounds, y_norm, x.dtype)

@@ -233,6 +233,24 @@ class FittedKernel:
                        C.byref(handle)))
         return FittedKernel(handle, dtype, n, d, nu)
 
+    def extend_with(self, x_train, y_train, ctx=None):
+        """FittedKernel::extend (fit.rs:33-68) at this model's theta on data whose leading rows are this model's training
+        rows (minimize.rs:629-644 appends the validation samples): reuses the factorisation of the kept 128-blocks, O(n^2 k)
+        instead of O(n^3).  Falls back to the full path when the prefix differs.  Sets `.incremental` on the result."""
+        lib = _lib.load()
+        ctx = ctx or default_context()
+        x = _lib.as_c(x_train, self.dtype)
+        y = _lib.as_c(y_train, self.dtype)
+        n, d = x.shape
+        assert d == self.d
+        handle = C.c_void_p()
+        inc = C.c_int(0)
+        ext = getattr(lib, f"hbegp_extend_from_{self._sfx}")
+        _lib.check(ext(ctx._h, self._h, _lib.aptr(x), _lib.aptr(y), n, C.byref(handle), C.byref(inc)))
+        fk = FittedKernel(handle, self.dtype, n, d, self.nu)
+        fk.incremental = bool(inc.value)
+        return fk
+
     def predict(self, x, want_variance=True):
         """predict() (predict.rs:7-52): returns (mean, variance or None, n_warn)."""
         lib = _lib.load()

@@ -126,6 +126,16 @@ int hbegp_extend_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, in
 int hbegp_extend_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta,
                      const double* lo, const double* hi, hbegp_model** model);
 
+/* extend at the theta of `prior`, a model fitted on a PREFIX of these rows (the caller appends its validation samples
+ * to the data the last model was built from, minimize.rs:629-644).  The leading floor(n_prior/128) diagonal blocks of L,
+ * L^-1 and K^-1 are reused: O(n^2 k) instead of the reference's O(n^3) refactorisation (fit.rs:33-68); same results to
+ * rounding.  Falls back to the full path when the prefix differs, n < n_prior or n_prior < 128.  *incremental (may be
+ * NULL) reports which path ran.  HBEGP_NOT_PD where the reference panics (fit.rs:55). */
+int hbegp_extend_from_f64(hbegp_ctx* ctx, hbegp_model* prior, const double* X, const double* y, int n, hbegp_model** model,
+                          int* incremental);
+int hbegp_extend_from_f32(hbegp_ctx* ctx, hbegp_model* prior, const float* X, const float* y, int n, hbegp_model** model,
+                          int* incremental);
+
 /* ---- model: mirrors predict() (predict.rs:7-52) and the FittedKernel fields -------------------------- */
 /* mean[m]; var[m] or NULL.  var = c + 1e-5 - rowsum((K* K^-1) o K*), negatives clamped to 0 (predict.rs:25-48);
  * it excludes s2 (the reference predicts the latent function).  *n_warn (may be NULL) = number of variances below

@@ -49,6 +49,7 @@ template <> struct Abi<double> {
   }
   static int extend(hbegp_ctx* c, const double* x, const double* y, int n, int d, double nu, const double* t, const double* lo,
                     const double* hi, hbegp_model** m) { return hbegp_extend_f64(c, x, y, n, d, nu, t, lo, hi, m); }
+  static int extend_from(hbegp_ctx* c, hbegp_model* p, const double* x, const double* y, int n, hbegp_model** m, int* inc) { return hbegp_extend_from_f64(c, p, x, y, n, m, inc); }
   static int predict(hbegp_model* m, const double* xs, int k, double* mean, double* var, int* w) { return hbegp_predict_f64(m, xs, k, mean, var, w); }
   static int get(hbegp_model* m, double* t, double* a, double* ki) { return hbegp_model_get_f64(m, t, a, ki); }
 };
@@ -59,6 +60,7 @@ template <> struct Abi<float> {
   }
   static int extend(hbegp_ctx* c, const float* x, const float* y, int n, int d, double nu, const double* t, const double* lo,
                     const double* hi, hbegp_model** m) { return hbegp_extend_f32(c, x, y, n, d, nu, t, lo, hi, m); }
+  static int extend_from(hbegp_ctx* c, hbegp_model* p, const float* x, const float* y, int n, hbegp_model** m, int* inc) { return hbegp_extend_from_f32(c, p, x, y, n, m, inc); }
   static int predict(hbegp_model* m, const float* xs, int k, float* mean, float* var, int* w) { return hbegp_predict_f32(m, xs, k, mean, var, w); }
   static int get(hbegp_model* m, double* t, float* a, float* ki) { return hbegp_model_get_f32(m, t, a, ki); }
 };
@@ -98,6 +100,18 @@ class FittedKernel {
     FittedKernel fk;
     fk.n_ = n; fk.d_ = d; fk.theta_.resize(d + 2);
     check(detail::Abi<A>::extend(ctx.get(), x, y, n, d, nu, theta.data(), b ? b->lo.data() : nullptr, b ? b->hi.data() : nullptr, &fk.h_));
+    check(detail::Abi<A>::get(fk.h_, fk.theta_.data(), nullptr, nullptr));
+    check(hbegp_model_info(fk.h_, nullptr, nullptr, nullptr, nullptr, &fk.lml_));
+    return fk;
+  }
+  // fit.rs:33-68 at this model's theta on data whose leading rows are this model's training rows (minimize.rs:629-644):
+  // reuses the factorisation of the unchanged 128-blocks; *incremental (optional) tells whether it could
+  FittedKernel extend_with(const Context& ctx, const A* x, const A* y, int n, bool* incremental = nullptr) const {
+    FittedKernel fk;
+    fk.n_ = n; fk.d_ = d_; fk.theta_.resize(d_ + 2);
+    int inc = 0;
+    check(detail::Abi<A>::extend_from(ctx.get(), h_, x, y, n, &fk.h_, &inc));
+    if (incremental) *incremental = inc != 0;
     check(detail::Abi<A>::get(fk.h_, fk.theta_.data(), nullptr, nullptr));
     check(hbegp_model_info(fk.h_, nullptr, nullptr, nullptr, nullptr, &fk.lml_));
     return fk;

@@ -38,6 +38,24 @@ int main() {
   } catch (const hbegp::NotPositiveDefinite&) {
     threw = true;
   }
+  // incremental extend through the mirror: 200 rows, prior on the first 150 (one kept 128-block), same alpha as from scratch
+  {
+    const int n = 200, n0 = 150, d = 2;
+    std::vector<double> X(n * d), Y(n);
+    unsigned s2 = 12345;
+    for (int i = 0; i < n * d; ++i) { s2 = s2 * 1664525u + 1013904223u; X[i] = (s2 >> 8) / 16777216.0; }
+    for (int i = 0; i < n; ++i) Y[i] = std::sin(3 * X[2 * i]) + X[2 * i + 1];
+    const std::vector<double> th = {std::log(1e-2), 0.0, std::log(0.5), std::log(0.7)};
+    auto prior = FittedKernel<double>::extend(ctx, X.data(), Y.data(), n0, d, 2.5, th);
+    bool inc = false;
+    auto a = prior.extend_with(ctx, X.data(), Y.data(), n, &inc);
+    auto f = FittedKernel<double>::extend(ctx, X.data(), Y.data(), n, d, 2.5, th);
+    if (!inc) ++bad;
+    const auto aa = a.alpha(), fa = f.alpha();
+    for (int i = 0; i < n; ++i)
+      if (std::fabs(aa[i] - fa[i]) > 1e-9 * (1.0 + std::fabs(fa[i]))) { ++bad; break; }
+    if (std::fabs(a.lml() - f.lml()) > 1e-9 * std::fabs(f.lml())) ++bad;
+  }
   std::printf("lml=%.6f amplitude=%.4f ell=%.4f noise=%.5f bad=%d threw=%d alpha0=%.4f\n", fk.lml(), fk.amplitude(), fk.length_scale()[0],
               fk.noise(), bad, (int)threw, fk.alpha()[0]);
   return (bad == 0 && threw) ? 0 : 1;

@@ -153,3 +153,48 @@ def test_fit_quality_matches_scipy_lbfgsb_on_the_oracle():
     at_hi = np.isclose(fk.theta, [b[1] for b in lnb]) & (g < 0)
     pg = np.where(at_lo | at_hi, 0.0, g)
     assert np.abs(pg).max() <= 1e-2 * max(1.0, abs(f))
+
+
+@pytest.mark.parametrize("n0,n,dtype", [(256, 300, np.float64), (300, 333, np.float64), (640, 1100, np.float64),
+                                         (130, 131, np.float64), (512, 512, np.float64), (384, 420, np.float32)])
+def test_incremental_extend_matches_the_full_path(n0, n, dtype):
+    """hbegp_extend_from: reuse the factorisation of the rows the prior model was built on.  Same
+    alpha, K^-1, lml and predictions as FittedKernel::extend from scratch (fit.rs:33-68), to rounding."""
+    w = synth.make_workload("C2", n=n)
+    X, y, theta = w["X"].astype(dtype), w["y"].astype(dtype), w["theta"]
+    prior = gpr.FittedKernel.extend(X[:n0], y[:n0], theta)
+    inc = prior.extend_with(X, y)
+    full = gpr.FittedKernel.extend(X, y, theta)
+    assert inc.incremental
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    assert abs(inc.lml - full.lml) <= tol * max(1.0, abs(full.lml))
+    ai, ki = inc.arrays()
+    af, kf = full.arrays()
+    np.testing.assert_allclose(ai, af, rtol=0, atol=tol * max(1.0, np.abs(af).max()))
+    np.testing.assert_allclose(ki, kf, rtol=0, atol=tol * np.abs(kf).max())
+    Xs = synth.candidates("C2", 50, w["d"]).astype(dtype)
+    mi, vi, _ = inc.predict(Xs)
+    mf, vf, _ = full.predict(Xs)
+    np.testing.assert_allclose(mi, mf, rtol=0, atol=tol * max(1.0, np.abs(mf).max()))
+    np.testing.assert_allclose(vi, vf, rtol=0, atol=tol * math.exp(theta[1]))
+    # a chain of incremental extends stays consistent
+    if n - n0 > 20:
+        mid = prior.extend_with(X[: n0 + 10], y[: n0 + 10])
+        again = mid.extend_with(X, y)
+        np.testing.assert_allclose(again.arrays(False)[0], af, rtol=0, atol=tol * max(1.0, np.abs(af).max()))
+
+
+def test_incremental_extend_falls_back_when_the_prefix_differs():
+    w = synth.make_workload("C2", n=400)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    prior = gpr.FittedKernel.extend(X[:300], y[:300], theta)
+    X2 = X.copy()
+    X2[17, 3] += 1e-3  # one changed entry in a kept block
+    res = prior.extend_with(X2, y)
+    assert not res.incremental
+    full = gpr.FittedKernel.extend(X2, y, theta)
+    np.testing.assert_allclose(res.arrays(False)[0], full.arrays(False)[0], rtol=0, atol=1e-12)
+    small = gpr.FittedKernel.extend(X[:100], y[:100], theta)  # fewer rows than one block: nothing to reuse
+    assert not small.extend_with(X, y).incremental
+    with pytest.raises(Exception):
+        prior.extend_with(X[:, :4], y)  # wrong feature count

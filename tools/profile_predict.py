@@ -18,4 +18,14 @@ for mm in (1, 32, m):
     t0 = time.perf_counter()
     for _ in range(5): fk.predict(Xs[:mm], want_variance=False)
     out[f"predict_mean_m{mm}_ms"] = (time.perf_counter() - t0) / 5 * 1e3
+# extend: full path vs incremental (prior built on all but the last `k` rows), warm workspaces
+for k in (16, 100):
+    prior = gpr.FittedKernel.extend(w["X"][:-k], w["y"][:-k], w["theta"])
+    for name, fn in (("full", lambda: gpr.FittedKernel.extend(w["X"], w["y"], w["theta"])),
+                     ("incremental", lambda: prior.extend_with(w["X"], w["y"]))):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(3): r = fn()
+        out[f"extend_{name}_k{k}_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+    assert r.incremental
 print(json.dumps(out))
