@@ -104,6 +104,25 @@ def test_recycled_workspaces_keep_triangular_operands_clean():
         del prob, fk
 
 
+@pytest.mark.parametrize("noise_rel,ell_scale", [(1e-4, 4.0), (1e-8, 8.0)])
+def test_ill_conditioned_kernel_matrix_stays_inside_the_bar(noise_rel, ell_scale):
+    """Long length scales and tiny noise: cond(K) = 2e5 / 8.5e6.  The engine solves the triangular systems with explicit
+    inverses; it must not lose digits against LAPACK there (tools/illcond_accuracy.py: both are 1e-10 from the truth)."""
+    w = synth.make_workload("C2", n=384)
+    X, y, theta = w["X"], w["y"], w["theta"].copy()
+    theta[0] = theta[1] + math.log(noise_rel)
+    theta[2:] += math.log(ell_scale)
+    s2, c, ell = split_theta(theta)
+    ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+    prob = gpr.Problem(X, y, nu=2.5)
+    lml, grad = prob.lml_with_gradient(theta)
+    assert abs(lml - ref["lml"]) <= F64_TOL * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["grad"]).max()))
+    alpha, kinv, _ = prob.results()
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=0, atol=F64_TOL * max(1.0, np.abs(ref["alpha"]).max()))
+    np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=F64_TOL * np.abs(ref["k_inv"]).max())
+
+
 @pytest.mark.parametrize("nu", [0.5, 1.5, 2.5])
 def test_all_matern_orders(nu):
     w = synth.make_workload("C1")
