@@ -586,10 +586,19 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
   };
 
   for (int p = 0; p < 8; ++p) {
-    if (wave == 0) {
+    // Elimination of panel p.  Wave 0 owns the 64-row window.  While p < 4 there are 64 - 16p rows beyond it: helper
+    // waves run the SAME elimination with lanes 0-15 on the diagonal rows again (redundantly, bitwise the same values) and
+    // lanes 16-63 on up to 48 of those far rows -- no communication, and the far rows are ready together with the window
+    // instead of in a separate substitution phase.  Helpers: wave 6 (far rows 0-47), and for p = 0 also wave 5 (48-63).
+    const int helper = (p < 4 && !(dbg & 4)) ? (wave == 6 ? 1 : ((wave == 5 && p == 0) ? 2 : 0)) : 0;
+    if (wave == 0 || helper) {
       if (!(dbg & 1)) {
         const int nwin = min(64, 128 - 16 * p);
-        const int row = 16 * p + ((lane < nwin) ? lane : 0);
+        const int nfar = 64 - 16 * p;                      // rows beyond the window (helpers only)
+        const int far = (helper - 1) * 48 + (lane - 16);  // index of this lane's far row
+        const bool mine = helper ? (lane >= 16 && far < nfar) : (lane < nwin);
+        const int row = helper ? ((lane < 16) ? 16 * p + lane : (far < nfar ? 16 * p + 64 + far : 16 * p))
+                               : 16 * p + ((lane < nwin) ? lane : 0);
         T a[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = As[row * S + p * 16 + j];
@@ -615,19 +624,19 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
 #pragma unroll
           for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, readlane(lk, j), a[j]);
         }
-        if (lane < nwin) {
+        if (mine) {
 #pragma unroll
           for (int j = 0; j < 16; ++j)
             if (lane >= 16 || j <= lane) As[row * S + p * 16 + j] = a[j];
         }
-        if (lane < 16) {
+        if (lane < 16 && !helper) {
           T dv = T(0);
 #pragma unroll
           for (int j = 0; j < 16; ++j) dv = (j == lane) ? a[j] : dv;
           ldiag[blk * NB + p * 16 + lane] = (TIO)dv;
           Rd[p * 16 + lane] = rinv_own;
         }
-        if (bad && lane == 0) atomicCAS(info, 0, 1 + blk * NB + p * 16);
+        if (bad && lane == 0 && !helper) atomicCAS(info, 0, 1 + blk * NB + p * 16);
       }
     } else if (p > 0) {
       // waves 1-7 meanwhile: Y_{p-1} (wave 7), block row p-2 of the inverse (waves 1-4, they own the scratch images),
@@ -638,7 +647,10 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
         for (int j = wave - 1; j < nx; j += 4) xinv_block(p - 2, j);
       const int tcount = 7 - p;
       const int nupd = (dbg & 4) ? 0 : tcount * (tcount + 1) / 2;
-      for (int u = wave - 1; u < nupd; u += 7) {
+      // the helper wave (6, while p < 4) is busy: the updates are dealt over the other six
+      const int nworkers = (p < 4 && !(dbg & 4)) ? 6 : 7;
+      const int wslot = (nworkers == 6 && wave == 7) ? 5 : wave - 1;
+      for (int u = wslot; u < nupd; u += nworkers) {
         const int li = tri_row(u), lj = u - li * (li + 1) / 2;
         update_block(p + 1 + li, p + 1 + lj, p - 1);
       }
@@ -647,38 +659,9 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
     if (p == 7) break;
     if (dbg & 4) continue;
 
-    if (p < 4) {
-      // (B) rows beyond wave 0's window (blocks p+4 .. 7): substitution against L_pp, lane = row
-      if (wave == 1) {
-        const int nfar = 64 - 16 * p;
-        const int row = 16 * p + 64 + ((lane < nfar) ? lane : 0);
-        T a[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = As[row * S + p * 16 + j];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const T lk = a[k] * Rd[p * 16 + k];
-          a[k] = lk;
-#pragma unroll
-          for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, As[(p * 16 + j) * S + p * 16 + k], a[j]);
-        }
-        if (lane < nfar) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) As[row * S + p * 16 + j] = a[j];
-        }
-      } else {
-        // window rows of block column p+1: blocks p+1 .. p+3, one per wave (0, 2, 3)
-        if (wave == 0 || wave == 2 || wave == 3) update_block(p + 1 + (wave == 0 ? 0 : wave - 1), p + 1, p);
-      }
-      __syncthreads();
-      // (C) far rows of block column p+1: blocks p+4 .. 7
-      for (int i = p + 4 + wave; i < 8; i += 8) update_block(i, p + 1, p);
-      __syncthreads();
-    } else {
-      // (C) block column p+1: every remaining row is inside the window
-      for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p);
-      __syncthreads();
-    }
+    // block column p+1 for every remaining block row (window rows from wave 0, far rows from the helpers)
+    for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p);
+    __syncthreads();
   }
 
   // ---------------- tail of the inverse: Y_7 and block row 6 of X, then block row 7 ----------------
