@@ -467,6 +467,10 @@ struct LeafGeom {
 // Tail: Y_7, block rows 6 and 7 of X.  fp64 MFMA for every 16x16x16 product.
 // T = arithmetic type of the block (always double: the block is latency-bound, so f32 problems are factored in f64 too),
 // TIO = element type in HBM.
+__device__ long long g_leaf_stamps[64];
+#define LEAF_STAMP(i) do { if ((dbg & 8) && t == 0) g_leaf_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+void read_leaf_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_leaf_stamps), sizeof(long long) * 64); }
+
 template <typename T, typename TIO>
 __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
                                                    TIO* __restrict__ ldiag, int* info, int dbg) {
@@ -514,6 +518,7 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
   }
   __syncthreads();
 
+  LEAF_STAMP(0);
   auto update_block = [&](int i, int j, int pp) {  // A[i,j] -= L[i,pp] L[j,pp]^T
     acc_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -531,7 +536,6 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
 
   // X = L^-1 block by block: X[i,i] = Y_ii ; X[i,j] = -Y_ii * sum_{k=j}^{i-1} L[i,k] X[k,j]  (i > j).
   // X[k,j] (k > j) is kept transposed in the upper part of As; block row i only needs rows < i, L[i,:] and Y_ii.
-  T* sc = Sc + ((wave - 1) & 3) * YB;  // waves 1-4 own a scratch image; only they run xinv_block
   auto xinv_block = [&](int i, int j) {
     acc_t acc = {0, 0, 0, 0};
     for (int k = j; k < i; ++k) {
@@ -544,9 +548,11 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
         acc = C::mfma(af, bf, acc);
       }
     }
-    // stage the sum through wave-private LDS to re-read it as a B operand
+    // stage the sum through LDS to re-read it as a B operand: in the place its result will occupy (the transposed image
+    // of X[i,j] in the upper part of As), so every wave can run this without a scratch image of its own
+    T* stage = &As[(j * 16) * S + i * 16];  // element (r, c) of the sum at stage[c * S + r]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[C::crow(lane, r) * YS + m16] = acc[r];
+    for (int r = 0; r < 4; ++r) stage[m16 * S + C::crow(lane, r)] = acc[r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -554,7 +560,7 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const T af = Ys[i * YB + m16 * YS + k4 * 4 + q4];
-      const T bf = sc[(k4 * 4 + q4) * YS + m16];
+      const T bf = stage[m16 * S + k4 * 4 + q4];
       res = C::mfma(af, bf, res);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -656,24 +662,25 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
       }
     }
     __syncthreads();
+    LEAF_STAMP(1 + 2 * p);
     if (p == 7) break;
     if (dbg & 4) continue;
 
     // block column p+1 for every remaining block row (window rows from wave 0, far rows from the helpers)
     for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p);
     __syncthreads();
+    LEAF_STAMP(2 + 2 * p);
   }
 
   // ---------------- tail of the inverse: Y_7 and block row 6 of X, then block row 7 ----------------
   if (!(dbg & 2)) {
     if (wave == 7) yinv_block(7);
-    else if (wave >= 1 && wave <= 4)
-      for (int j = wave - 1; j < 6; j += 4) xinv_block(6, j);
+    else if (wave >= 1) xinv_block(6, wave - 1);   // six blocks, waves 1-6
     __syncthreads();
-    if (wave >= 1 && wave <= 4)
-      for (int j = wave - 1; j < 7; j += 4) xinv_block(7, j);
+    if (wave >= 1) xinv_block(7, wave - 1);        // seven blocks, waves 1-7
     __syncthreads();
   }
+  LEAF_STAMP(20);
   // diagonal sub-blocks of X
   for (int c = t; c < 8 * 256; c += 512) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;

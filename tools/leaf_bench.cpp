@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include "engine.hpp"
-namespace hbegp { void init_kernels(); }
+namespace hbegp { void init_kernels(); void read_leaf_stamps(long long* out); }
 using namespace hbegp;
 int main() {
   const int nb = 32, np = nb * 128;
@@ -32,6 +32,21 @@ int main() {
     int hinfo; hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost); hipMemset(info, 0, 4);
     printf("dbg=%d (skip diag=%d phase2=%d mfma-phase1=%d): %.2f us per leaf (info=%d)\n", dbg, dbg & 1, (dbg >> 1) & 1, (dbg >> 2) & 1,
            ms * 1000 / nb, hinfo);
+  }
+  // per-phase cycle stamps of one block (dbg bit 3)
+  for (int extra : {0, 4, 2, 6, 1}) {
+  hipMemcpy(W1, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+  launch_leaf<double>(W1, W2, np, 0, ld, info, 0, 8 | extra);
+  printf("dbg=%d ", extra);
+  hipDeviceSynchronize();
+  long long st[64];
+  read_leaf_stamps(st);
+  printf("cycles: load->0");
+  for (int p = 0; p < 8; ++p) {
+    printf(" | p%d: phase1 %lld", p, st[1 + 2 * p] - (p == 0 ? st[0] : st[2 * p]));
+    if (p < 7) printf(" phase2 %lld", st[2 + 2 * p] - st[1 + 2 * p]);
+  }
+  printf(" | tail %lld | total %lld\n", st[20] - st[15], st[20] - st[0]);
   }
   return 0;
 }
