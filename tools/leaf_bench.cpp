@@ -34,7 +34,7 @@ int main() {
            ms * 1000 / nb, hinfo);
   }
   // per-phase cycle stamps of one block (dbg bit 3)
-  for (int extra : {0, 4, 2, 6, 1}) {
+  for (int extra : {0, 3, 1, 2}) {
   hipMemcpy(W1, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   launch_leaf<double>(W1, W2, np, 0, ld, info, 0, 8 | extra);
   printf("dbg=%d ", extra);
