@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HBEGP_VERSION 100 /* 0.1.0 */
+#define HBEGP_VERSION 101 /* 0.1.1: + hbegp_extend_from_* */
 
 enum {
   HBEGP_OK = 0,
