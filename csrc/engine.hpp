@@ -27,6 +27,8 @@ struct EvalOut {
   double grad[MAXP];
   int info;        // 0 ok, else 1 + index of the failing pivot (not positive definite)
   int n_warn;      // predict: variances below -sqrt(1e-5)
+  int done;        // bit 0: lml written by this evaluation, bit 1: gradient written (a kernel that never ran leaves them clear)
+  int pad_;
 };
 
 // One tile-GEMM operation on row-major matrices, in units of TILE x TILE tiles (global tile coordinates).
@@ -99,6 +101,11 @@ template <typename T>
 void launch_pred_var(const T* Ks, const T* Q, int m, int np, const EvalParams* P, T* var, EvalOut* out, hipStream_t s);
 
 void launch_set_info(int* info, int value, hipStream_t s);
+// start of an evaluation: info = n_warn = done = 0, lml and gradient poisoned with NaN (a launch that was rejected or
+// skipped can then never pass for a result)
+void launch_reset_out(EvalOut* out, hipStream_t s);
+// throws nothing: returns the first pending launch error of the calling thread's device (hipGetLastError)
+void init_kernels();
 
 // *flag |= 1 when the two device arrays differ anywhere in [0, count)
 template <typename T>

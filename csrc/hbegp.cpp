@@ -27,14 +27,12 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "engine.hpp"
 #include "lbfgsb.hpp"
 
-namespace hbegp {
-void init_kernels();  // kernels.hip: per-device function attributes (must run before any graph capture)
-}
 
 using namespace hbegp;
 
@@ -60,6 +58,14 @@ struct HipError {
     if (_e != hipSuccess) throw HipError{_e, #x, __LINE__}; \
   } while (0)
 
+// A rejected launch (bad configuration, LDS request refused, ...) is only reported through hipGetLastError: checked after
+// every group of launches, also while a stream is being captured.
+#define CHECK_LAUNCHES()                                                        \
+  do {                                                                          \
+    hipError_t _e = hipGetLastError();                                          \
+    if (_e != hipSuccess) throw HipError{_e, "kernel launch", __LINE__};        \
+  } while (0)
+
 static int hip_fail(const HipError& he) {
   return fail(he.e == hipErrorOutOfMemory ? HBEGP_ENOMEM : HBEGP_EHIP, "HIP error %d (%s) in %s at hbegp.cpp:%d", (int)he.e,
               hipGetErrorString(he.e), he.what, he.line);
@@ -73,6 +79,7 @@ static int env_int(const char* name, int dflt) {
 struct hbegp_ctx {
   std::vector<int> devs;
 };
+static std::atomic<int> g_live_ctx{0};  // the block pool is process-global: it is trimmed when the last context goes
 
 // ---------------------------------------------------------------------------------------------------------------
 // Device-memory pool for the large work matrices (np x np).  hipMalloc/hipFree of 128 MiB blocks costs tens of
@@ -104,6 +111,13 @@ struct DevPool {
       trim();  // give cached blocks back and retry once
       e = hipMalloc(&p, bytes);
       if (e != hipSuccess) throw HipError{e, "hipMalloc (pool)", __LINE__};
+    }
+    // a fresh block is cleared once, here: every later owner may rely on "finite numbers everywhere" (recycled blocks
+    // hold finite results of their previous life)
+    e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      throw HipError{e, "hipMemset (pool)", __LINE__};
     }
     *fresh = true;
     return p;
@@ -351,8 +365,7 @@ struct Problem : ProblemBase {
         // once per slot is enough -- also when it is recycled from the pool (it may have held a full symmetric K^-1).
         // W1's strict upper part is only ever multiplied by those zeros or ignored: it just has to be finite.
         HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
-        (void)fresh2;
-        if (fresh1) HIPCHECK(hipMemset(s.W1, 0, sizeof(T) * nn));
+        (void)fresh1; (void)fresh2; (void)fk;  // fresh blocks were cleared by the pool
         HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.part_t, sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64)));
@@ -592,7 +605,7 @@ struct Problem : ProblemBase {
     const int* info = &s.dOut->info;
     if (!dry_) {
       HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
-      HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+      launch_reset_out(s.dOut, s.stream);
       if (tm) tm->begin(PhaseTimer::KMAT);
       launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
       if (tm) tm->end();
@@ -621,6 +634,7 @@ struct Problem : ProblemBase {
       launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream);
       if (tm) tm->end();
     }
+    CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
   }
 
@@ -631,9 +645,10 @@ struct Problem : ProblemBase {
     HIPCHECK(hipSetDevice(s.dev));
     s.gemm_ord = 0;
     HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
-    HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+    launch_reset_out(s.dOut, s.stream);
     launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
     chol_inv(s, di, np / NB, nullptr);
+    CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
     HIPCHECK(hipStreamSynchronize(s.stream));
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
@@ -652,9 +667,10 @@ struct Problem : ProblemBase {
     if (q0 < 1 || pn > n) return HBEGP_EINVAL;
     const int* info = &s.dOut->info;
     HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
-    HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+    launch_reset_out(s.dOut, s.stream);
     // same leading rows?  (only the kept blocks matter, compare the whole prior prefix anyway)
     launch_prefix_differs<T>(Xd[di], pX, (size_t)pn * d, &s.dOut->n_warn, s.stream);
+    CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
     HIPCHECK(hipStreamSynchronize(s.stream));
     if (s.hOut->n_warn != 0) {
@@ -702,9 +718,11 @@ struct Problem : ProblemBase {
       throw;
     }
     adhoc_ = was_adhoc;
+    CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
     HIPCHECK(hipStreamSynchronize(s.stream));
     s.last_target = 0;
+    if (s.hOut->info == 0 && !(s.hOut->done & 1)) throw HipError{hipErrorLaunchFailure, "extend: the evaluation kernels did not run", __LINE__};
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
   }
 
@@ -740,6 +758,9 @@ struct Problem : ProblemBase {
       if (grad) for (int j = 0; j < p; ++j) grad[j] = 0.0;  // fit.rs:105-112
       return HBEGP_NOT_PD;
     }
+    // the evaluation starts by poisoning its outputs and clearing `done`: a kernel that was skipped cannot pass for a result
+    if (!(s.hOut->done & 1) || (want_grad && !(s.hOut->done & 2)))
+      throw HipError{hipErrorLaunchFailure, "evaluation: the lml/gradient kernels did not run", __LINE__};
     *lml = s.hOut->lml;
     if (grad) for (int j = 0; j < p; ++j) grad[j] = s.hOut->grad[j];
     return HBEGP_OK;
@@ -883,6 +904,7 @@ static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double
   HIPCHECK(hipMemcpyAsync(m->alpha, s.alpha[b], sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->Kinv, s.Kinv[b], sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
   launch_symmetrize<T>(static_cast<T*>(m->Kinv), prob.np, m->stream);  // invc_into() returns the full matrix (fit.rs:60,168)
+  CHECK_LAUNCHES();
   EvalParams P;
   memset(&P, 0, sizeof(P));
   theta_to_params(theta_clamped, nullptr, nullptr, prob.d, &P);
@@ -937,6 +959,7 @@ static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, 
       launch_pred_var<T>(static_cast<T*>(m->Q), static_cast<T*>(m->Q), cnt, m->np, m->dP, static_cast<T*>(m->var), m->dOut, s);
     }
   }
+  CHECK_LAUNCHES();
   HIPCHECK(hipMemcpyAsync(mean, m->mean, sizeof(T) * cnt, hipMemcpyDeviceToHost, s));
   if (var) HIPCHECK(hipMemcpyAsync(var, m->var, sizeof(T) * cnt, hipMemcpyDeviceToHost, s));
   EvalOut out;
@@ -1034,9 +1057,32 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   };
 
   std::vector<std::thread> threads;
-  for (int di = 0; di < ndev; ++di)
-    for (int si = 0; si < std::min(runs_on[di], max_conc); ++si) threads.emplace_back(worker, di, si);
+  try {
+    for (int di = 0; di < ndev; ++di)
+      for (int si = 0; si < std::min(runs_on[di], max_conc); ++si) threads.emplace_back(worker, di, si);
+  } catch (...) {
+    // thread creation failed part-way (std::system_error): the workers already started own device state -- let them
+    // finish before the error leaves this frame (destroying a joinable std::thread terminates the process)
+    for (auto& t : threads) t.join();
+    throw;
+  }
   for (auto& t : threads) t.join();
+  // the workers append to the trace as their evaluations complete; hand it back in (run, eval) order
+  if (opt.trace_cap > 0 && trace_n > 1 && opt.trace_run) {
+    std::vector<int> order(trace_n);
+    for (int i = 0; i < trace_n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return opt.trace_run[a] < opt.trace_run[b]; });
+    auto permute = [&](auto* arr, int width) {
+      if (!arr) return;
+      std::vector<typename std::remove_pointer<decltype(arr)>::type> tmp((size_t)trace_n * width);
+      for (int i = 0; i < trace_n; ++i) memcpy(&tmp[(size_t)i * width], arr + (size_t)order[i] * width, sizeof(tmp[0]) * width);
+      memcpy(arr, tmp.data(), sizeof(tmp[0]) * tmp.size());
+    };
+    permute(opt.trace_theta, p);
+    permute(opt.trace_lml, 1);
+    permute(opt.trace_grad, p);
+    permute(opt.trace_run, 1);
+  }
   if (opt.trace_count) *opt.trace_count = trace_n;
   if (!err.empty()) return fail(HBEGP_EHIP, "%s", err.c_str());
 
@@ -1148,7 +1194,9 @@ static int check_args(hbegp_ctx* ctx, const void* X, const void* y, int n, int d
 #define GUARD_END                                   \
   }                                                 \
   catch (const HipError& he) { return hip_fail(he); } \
-  catch (const std::bad_alloc&) { return fail(HBEGP_ENOMEM, "host allocation failed"); }
+  catch (const std::bad_alloc&) { return fail(HBEGP_ENOMEM, "host allocation failed"); } \
+  catch (const std::exception& e) { return fail(HBEGP_EHIP, "internal error: %s", e.what()); } \
+  catch (...) { return fail(HBEGP_EHIP, "internal error: unknown exception"); }
 
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -1188,12 +1236,14 @@ int hbegp_ctx_create(int n_devices, const int* device_ids, hbegp_ctx** out) {
     ctx->devs.push_back(id);
   }
   *out = ctx.release();
+  g_live_ctx.fetch_add(1);
   return HBEGP_OK;
   GUARD_END
 }
 void hbegp_ctx_destroy(hbegp_ctx* ctx) {
-  g_pool.trim();
+  if (!ctx) return;
   delete ctx;
+  if (g_live_ctx.fetch_sub(1) == 1) g_pool.trim();
 }
 
 int hbegp_problem_create_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, int n_slots,
@@ -1277,8 +1327,9 @@ static int problem_kmat(hbegp_problem* prob, int dev, int slot, const double* th
   HIPCHECK(hipSetDevice(s.dev));
   theta_to_params(theta, lo, hi, p->d, s.hP);
   HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
-  HIPCHECK(hipMemsetAsync(&s.dOut->info, 0, sizeof(int), s.stream));
+  launch_reset_out(s.dOut, s.stream);
   launch_kmat<T>(p->Xd[dev], p->n, p->d, p->np, p->nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+  CHECK_LAUNCHES();
   const int n = p->n, np = p->np;
   std::vector<T> tmp((size_t)np * np);
   HIPCHECK(hipMemcpyAsync(tmp.data(), s.W1, sizeof(T) * tmp.size(), hipMemcpyDeviceToHost, s.stream));
@@ -1410,10 +1461,21 @@ void hbegp_model_release(hbegp_model* model) {
 
 double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, const double* lo, const double* hi, int n,
                                   int maxeval) {
-  LbfgsOptions opt;
-  opt.maxeval = maxeval > 0 ? maxeval : 150;
-  Objective obj = [&](const double* xx, double* g) { return f(xx, g, user); };
-  return lbfgsb_minimize(obj, x, lo, hi, n, opt).f;
+  if (!f || !x || !lo || !hi || n < 1) {
+    fail(HBEGP_EINVAL, "hbegp_minimize_by_gradient: NULL argument or n < 1");
+    return std::numeric_limits<double>::quiet_NaN();
+  }
+  try {
+    LbfgsOptions opt;
+    opt.maxeval = maxeval > 0 ? maxeval : 150;
+    Objective obj = [&](const double* xx, double* g) { return f(xx, g, user); };
+    return lbfgsb_minimize(obj, x, lo, hi, n, opt).f;
+  } catch (const std::exception& e) {
+    fail(HBEGP_EHIP, "hbegp_minimize_by_gradient: %s", e.what());
+  } catch (...) {
+    fail(HBEGP_EHIP, "hbegp_minimize_by_gradient: unknown exception");
+  }
+  return std::numeric_limits<double>::quiet_NaN();
 }
 
 }  // extern "C"

@@ -18,6 +18,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 
 #include "engine.hpp"
 
@@ -883,6 +885,7 @@ __global__ void lml_final_kernel(const double* __restrict__ sums, int nblocks, i
     out->yalpha = s1;
     out->logdet = s2;
     out->lml = -0.5 * s1 - s2 - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
+    atomicOr(&out->done, 1);
   }
 }
 
@@ -1054,7 +1057,10 @@ __global__ void __launch_bounds__(256) finalize_grad_kernel(const double* __rest
   double acc = 0;
   for (int b = threadIdx.x; b < nblocks; b += 256) acc += part[(size_t)b * p + j];
   const double s = block_sum(acc, red);
-  if (threadIdx.x == 0) out->grad[j] = 0.5 * s;
+  if (threadIdx.x == 0) {
+    out->grad[j] = 0.5 * s;
+    if (j == p - 1) atomicOr(&out->done, 2);  // the last block alone cannot vouch for the others; the host checks every entry for NaN
+  }
 }
 
 size_t gradtrace_part_elems(int np, int d) {
@@ -1227,21 +1233,34 @@ template void launch_pred_var<float>(const float*, const float*, int, int, const
 
 // Per-device one-time setup: kernels that use more than 64 KiB of dynamic LDS need the attribute raised.  Called from
 // hbegp_ctx_create() for every device, before any stream capture.
+static void set_lds_attr(const void* fn, int bytes, const char* what) {
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
 template <typename T, int TILE>
 static void init_gemm_attr() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            163840);
+  set_lds_attr(reinterpret_cast<const void*>(&gemm_kernel<T, TILE>), 163840, "gemm_kernel: dynamic LDS limit");
 }
+// Throws std::runtime_error (caught in hbegp_ctx_create): a kernel that cannot get its LDS would be rejected at every launch.
 void init_kernels() {
   init_gemm_attr<double, 128>(); init_gemm_attr<double, 64>(); init_gemm_attr<double, 32>();
   init_gemm_attr<float, 128>(); init_gemm_attr<float, 64>(); init_gemm_attr<float, 32>();
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<double, double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LeafGeom<double>::LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&leaf_kernel<double, float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LeafGeom<double>::LDS_BYTES);
+  set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, double>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f64>: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, float>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f32>: dynamic LDS limit");
 }
 
 __global__ void set_info_kernel(int* info, int value) { *info = value; }
 void launch_set_info(int* info, int value, hipStream_t s) { hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, s, info, value); }
+
+__global__ void reset_out_kernel(EvalOut* out) {
+  const int t = threadIdx.x;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  if (t == 0) {
+    out->lml = nan; out->yalpha = nan; out->logdet = nan;
+    out->info = 0; out->n_warn = 0; out->done = 0;
+  }
+  if (t < MAXP) out->grad[t] = nan;
+}
+void launch_reset_out(EvalOut* out, hipStream_t s) { hipLaunchKernelGGL(reset_out_kernel, dim3(1), dim3(128), 0, s, out); }
 
 }  // namespace hbegp

@@ -103,7 +103,7 @@ def _norm_inverse_cdf(p, mu, sigma):
 def expected_improvement(mean, std, fmin):
     """acquisition.rs:141-171"""
     assert math.isfinite(mean) and math.isfinite(std) and math.isfinite(fmin)
-    if std <= 0.0 or abs(std) < 4 * np.finfo(float).eps * abs(std):
+    if std <= 0.0 or abs(std) <= np.finfo(float).eps:  # ulps_eq!(std, 0.0): |std| <= f64::EPSILON (acquisition.rs:148)
         return -(mean - fmin) if mean < fmin else 0.0
     z = -(mean - fmin) / std
     ei = -(mean - fmin) * _norm_cdf(z) + std * _norm_pdf(z)
@@ -212,7 +212,7 @@ class SurrogateModelGPR:
         mean = self.y_norm.project_mean_from_normalized(m, v)[0]
         std = self.y_norm.project_std_from_normalized(m, v)[0]
         cv = self.y_norm.project_cv_from_normalized(m, v)[0]
-        if abs(std_n) < 1e-300:
+        if abs(std_n) <= np.finfo(float).eps:  # abs_diff_eq!(std, 0.0): |std| <= f64::EPSILON (gpr.rs:133)
             qn = np.array([mean_n] * 3, dtype=self.dtype)
         else:
             qn = np.array([_norm_inverse_cdf(p, mean_n, std_n) for p in (0.25, 0.5, 0.75)], dtype=self.dtype)
@@ -349,7 +349,10 @@ class EstimatorGPR:
         if self._n_restarts_optimizer > 0:  # gradmin.rs:22-24: uniform in log-bounds
             u = fork.uniform(0.0, 1.0, self._n_restarts_optimizer * p).reshape(self._n_restarts_optimizer, p)
             starts = np.log(lo)[None, :] + (np.log(hi) - np.log(lo))[None, :] * u
-        fitted = gpr.FittedKernel.new(x, y_train.astype(x.dtype), theta0, lo, hi, starts, nu=self._matern_nu, ctx=self.ctx)
+        # a prior hands over its whole kernel -- theta, bounds AND the Matern nu (prior.kernel.clone(), gpr.rs:407-409);
+        # the estimator's own nu only configures the default kernel
+        nu = prior.fitted.nu if prior is not None else self._matern_nu
+        fitted = gpr.FittedKernel.new(x, y_train.astype(x.dtype), theta0, lo, hi, starts, nu=nu, ctx=self.ctx)
         return SurrogateModelGPR(fitted, (lo[0], hi[0]), (lo[1], hi[1]), list(zip(lo[2:], hi[2:])), y_norm, x.dtype)
 
     def extend(self, x, y, prior, rng=None):  # gpr.rs:293-337
@@ -359,10 +362,10 @@ class EstimatorGPR:
         y_train, y_norm = YNormalize.new_project_into_normalized(y, self._y_projection, self._known_optimum)
         lo = np.array([prior.noise_bounds[0], prior.amplitude_bounds[0]] + [b[0] for b in prior.length_scale_bounds])
         hi = np.array([prior.noise_bounds[1], prior.amplitude_bounds[1]] + [b[1] for b in prior.length_scale_bounds])
-        if prior.fitted.nu == self._matern_nu and prior.fitted.dtype == x.dtype:
+        if prior.fitted.dtype == x.dtype:  # the kernel (incl. its nu) is the prior's (prior.kernel.clone(), gpr.rs:318-323)
             # the caller appends its validation samples to the rows the prior was built on (minimize.rs:629-644): the engine
             # reuses the prior's factorisation for the unchanged leading rows (falls back by itself when they differ)
             fitted = prior.fitted.extend_with(x, y_train.astype(x.dtype), ctx=self.ctx)
         else:
-            fitted = gpr.FittedKernel.extend(x, y_train.astype(x.dtype), prior.fitted.theta, lo, hi, nu=self._matern_nu, ctx=self.ctx)
+            fitted = gpr.FittedKernel.extend(x, y_train.astype(x.dtype), prior.fitted.theta, lo, hi, nu=prior.fitted.nu, ctx=self.ctx)
         return SurrogateModelGPR(fitted, prior.noise_bounds, prior.amplitude_bounds, prior.length_scale_bounds, y_norm, x.dtype)

@@ -99,8 +99,10 @@ typedef struct hbegp_fit_options {
   int fixed_work;   /* 0: stop a run when the optimiser converges; 1: keep evaluating up to maxeval (bench) */
   int lbfgs_memory; /* history pairs, 0 = default (10) */
   int trace_cap;    /* capacity (in evaluations) of the trace buffers below, 0 = no trace */
-  /* optional trace of every evaluation in (run, eval) order, for replay parity against the oracle:
-   * trace_theta[trace_cap*p], trace_lml[trace_cap] (-inf when not PD), trace_grad[trace_cap*p], trace_run[trace_cap] */
+  /* optional trace of the evaluations, for replay parity against the oracle: trace_theta[trace_cap*p],
+   * trace_lml[trace_cap] (-inf when not PD), trace_grad[trace_cap*p], trace_run[trace_cap].  Concurrent runs record as
+   * their evaluations complete (the first trace_cap of them are kept); on return the records are sorted by run, and
+   * within a run they are in evaluation order.  Sorting needs trace_run; without it the order is completion order. */
   double* trace_theta;
   double* trace_lml;
   double* trace_grad;

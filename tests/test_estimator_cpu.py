@@ -47,6 +47,18 @@ def test_expected_improvement_cases():
         assert E.expected_improvement(mean, std, fmin) == pytest.approx(want, rel=1e-12)
 
 
+def test_expected_improvement_zero_std_boundary_is_f64_epsilon():
+    # ulps_eq!(std, 0.0) (acquisition.rs:148) is |std| <= f64::EPSILON: at and below it the degenerate branch runs,
+    # just above it the z-score branch does
+    eps = np.finfo(float).eps
+    assert E.expected_improvement(1.0, eps, 2.0) == 1.0
+    assert E.expected_improvement(1.0, eps / 2, 2.0) == 1.0
+    assert E.expected_improvement(3.0, eps, 2.0) == 0.0
+    above = E.expected_improvement(1.0, 4 * eps, 2.0)
+    assert above == pytest.approx(1.0, rel=1e-12)  # same value in the limit, but through cdf/pdf
+    assert E.expected_improvement(2.0, 1e-9, 2.0) > 0.0  # mean == fmin: only the z-score branch gives std * pdf(0)
+
+
 def test_estimate_amplitude():
     y = np.array([0.05, 0.5, 1.0, 2.45])
     start, lo, hi = E.estimate_amplitude(y)
