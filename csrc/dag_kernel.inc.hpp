@@ -1,0 +1,263 @@
+// dag_kernel.inc.hpp — included at the end of kernels.hip (inside namespace hbegp).
+//
+// Device-scheduled Cholesky + inverse-factor recursion: ONE persistent launch replaces the chain of diagonal-block and
+// tile-GEMM launches of chol_inv (lml.rs:47 `factorizec` + the factor's inverse that lml.rs:62 `invc` needs).
+//
+//   * Workgroups of 512 threads (one per CU: the diagonal-block task needs the whole LDS) pull tasks from an ordered
+//     queue with one returning agent-scope atomic add.  A task is a 128x128 diagonal block (leaf_body), or a 128x64 /
+//     64x64 output tile of one of the recursion's products over its whole contraction range.
+//   * Dependencies are counters in global memory: a task waits until each of its (at most DAG_MAXWAIT) counters has
+//     reached its value, and bumps its own counter once its results are visible.  The queue order is a topological
+//     order of the graph (host: dag_plan.hpp, checked by dag_plan_validate), so whichever workgroups are resident make
+//     progress -- nothing assumes co-residency, dispatch order or placement.
+//   * Visibility (CDNA4: per-CU L1 is never refreshed by other CUs' stores, per-XCD L2s are write-back): results are
+//     stored write-through (sc1), every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a
+//     barrier, then one lane bumps the counter.  The consumer polls with relaxed agent-scope loads from one lane, runs
+//     ONE agent-scope acquire (buffer_inv sc1: drops this CU's L1 lines), waits for it, and the workgroup meets at a
+//     barrier before any wave loads operands with plain loads.
+//   * Every wait is bounded (2 s of the constant 100 MHz clock): on expiry the task index is recorded, info becomes
+//     DAG_INFO_TIMEOUT and every workgroup drains out -- a scheduling bug ends in an error code, not in a hung GPU.
+//   * Not positive definite (info > 0, set by a diagonal block): later tasks skip their work but still bump their
+//     counters, so the queue drains at once.
+//
+// Arithmetic per output element is the same sequence of MFMA accumulations as in gemm_kernel (k ascending in steps of
+// four, operands identical), so results are bitwise equal to the launch-per-product path.
+
+template <typename T, int TA, int TB>
+struct DagGeom {
+  using C = Cfg<T>;
+  static constexpr int NT = 512;
+  static constexpr int BK = C::BK;
+  static constexpr int SK = BK + 2;                    // LDS row stride, operand stored [outer][k]
+  static constexpr int SMA = TA + 16, SMB = TB + 16;   // LDS row stride, operand stored [k][outer]
+  static constexpr int LDSA = (TA * SK > BK * SMA) ? TA * SK : BK * SMA;
+  static constexpr int LDSB = (TB * SK > BK * SMB) ? TB * SK : BK * SMB;
+  static constexpr int NCHA = TA * BK / C::VEC / NT, NCHB = TB * BK / C::VEC / NT;  // 16-byte chunks per thread per stage
+  static constexpr int WM = 4, WN = 2;                 // wave grid
+  static constexpr int TMA = TA / WM / 16, TMB = TB / WN / 16;  // 16x16 MFMA blocks per wave
+  static_assert(NCHA >= 1 && NCHB >= 1 && TMA >= 1 && TMB >= 1, "tile too small for 512 threads");
+};
+
+constexpr int DAG_LDS_CTL_OFF = (int)((LeafGeom<double>::LDS_BYTES + 15) / 16 * 16);
+constexpr int DAG_LDS_BYTES = DAG_LDS_CTL_OFF + 64;
+static_assert(DAG_LDS_BYTES <= 163840, "the diagonal block and the control words must fit the CU's LDS");
+
+template <typename T, int TA, int TB>
+__device__ __forceinline__ void dag_gemm_tile(const DagTask& tk, T* __restrict__ W1, T* __restrict__ W2, int ld, char* smem_raw) {
+  using C = Cfg<T>;
+  using G = DagGeom<T, TA, TB>;
+  using vec_t = typename C::vec_t;
+  using acc_t = typename C::acc_t;
+  constexpr int VEC = C::VEC, BK = G::BK, SK = G::SK, SMA = G::SMA, SMB = G::SMB, NCHA = G::NCHA, NCHB = G::NCHB;
+  constexpr int TMA = G::TMA, TMB = G::TMB, NT = G::NT;
+
+  const int flags = tk.flags;
+  const int akm = (flags & DAGF_AKM) ? 1 : 0, bkm = (flags & DAGF_BKM) ? 1 : 0;
+  const T* Ag = (flags & DAGF_ABUF) ? W2 : W1;
+  const T* Bg = (flags & DAGF_BBUF) ? W2 : W1;
+  T* Cg = (flags & DAGF_CBUF) ? W2 : W1;
+  const int row0 = tk.row0, col0 = tk.col0, kbeg = tk.kbeg;
+  const int nstages = (tk.kend - tk.kbeg) / BK;
+
+  T* lds = reinterpret_cast<T*>(smem_raw);  // [A buf0 | A buf1 | B buf0 | B buf1]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  constexpr int CPK = BK / VEC;                   // chunks per slab row, operand stored [outer][k]
+  constexpr int RPP_K = NT / CPK;                 // slab rows per pass
+  constexpr int CPRA = TA / VEC, CPRB = TB / VEC; // chunks per slab row, operand stored [k][outer]
+  constexpr int RPP_MA = NT / CPRA, RPP_MB = NT / CPRB;
+  const int a_r0 = akm ? t / CPRA : t / CPK, a_c0 = akm ? (t % CPRA) * VEC : (t % CPK) * VEC;
+  const int b_r0 = bkm ? t / CPRB : t / CPK, b_c0 = bkm ? (t % CPRB) * VEC : (t % CPK) * VEC;
+  const int a_rpp = akm ? RPP_MA : RPP_K, b_rpp = bkm ? RPP_MB : RPP_K;
+  const int a_lds0 = a_r0 * (akm ? SMA : SK) + a_c0, a_ldsq = a_rpp * (akm ? SMA : SK);
+  const int b_lds0 = 2 * G::LDSA + b_r0 * (bkm ? SMB : SK) + b_c0, b_ldsq = b_rpp * (bkm ? SMB : SK);
+
+  const T* pA = Ag + (akm ? (size_t)(kbeg + a_r0) * ld + row0 + a_c0 : (size_t)(row0 + a_r0) * ld + kbeg + a_c0);
+  const T* pB = Bg + (bkm ? (size_t)(kbeg + b_r0) * ld + col0 + b_c0 : (size_t)(col0 + b_r0) * ld + kbeg + b_c0);
+  const size_t a_step = akm ? (size_t)BK * ld : (size_t)BK, b_step = bkm ? (size_t)BK * ld : (size_t)BK;
+  const size_t a_qs = (size_t)a_rpp * ld, b_qs = (size_t)b_rpp * ld;
+
+  vec_t ra0[NCHA], rb0[NCHB], ra1[NCHA], rb1[NCHB];
+  auto load_stage = [&](vec_t (&ra)[NCHA], vec_t (&rb)[NCHB]) {
+#pragma unroll
+    for (int q = 0; q < NCHA; ++q) ra[q] = *reinterpret_cast<const vec_t*>(pA + q * a_qs);
+#pragma unroll
+    for (int q = 0; q < NCHB; ++q) rb[q] = *reinterpret_cast<const vec_t*>(pB + q * b_qs);
+    pA += a_step;
+    pB += b_step;
+  };
+  auto store_stage = [&](int buf, vec_t (&ra)[NCHA], vec_t (&rb)[NCHB]) {
+#pragma unroll
+    for (int q = 0; q < NCHA; ++q) C::lds_store(lds + buf * G::LDSA + a_lds0 + q * a_ldsq, ra[q]);
+#pragma unroll
+    for (int q = 0; q < NCHB; ++q) C::lds_store(lds + buf * G::LDSB + b_lds0 + q * b_ldsq, rb[q]);
+  };
+
+  acc_t acc[TMA][TMB];
+#pragma unroll
+  for (int a = 0; a < TMA; ++a)
+#pragma unroll
+    for (int b = 0; b < TMB; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+
+  const int soA = akm ? 1 : SK, skA = akm ? SMA : 1;
+  const int soB = bkm ? 1 : SK, skB = bkm ? SMB : 1;
+  const int fa0 = (wm * (TA / G::WM) + (lane & 15)) * soA + (lane >> 4) * skA;
+  const int fb0 = 2 * G::LDSA + (wn * (TB / G::WN) + (lane & 15)) * soB + (lane >> 4) * skB;
+
+  // Same software pipeline as gemm_kernel's 64-tile: global loads two stages ahead in two register sets, LDS double
+  // buffer, the fragments of a whole stage in registers, the next stage's first fragments read under the MFMAs of the
+  // last k-step.
+  constexpr int NK = BK / 4;
+  T fa[NK][TMA], fb[NK][TMB];
+  auto read_frags = [&](int buf, int k4) {
+    const int ia = buf * G::LDSA + fa0 + k4 * 4 * skA, ib = buf * G::LDSB + fb0 + k4 * 4 * skB;
+#pragma unroll
+    for (int a = 0; a < TMA; ++a) fa[k4][a] = lds[ia + a * 16 * soA];
+#pragma unroll
+    for (int b2 = 0; b2 < TMB; ++b2) fb[k4][b2] = lds[ib + b2 * 16 * soB];
+  };
+  auto mfma_step = [&](int k4) {
+#pragma unroll
+    for (int a = 0; a < TMA; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < TMB; ++b2) acc[a][b2] = C::mfma(fa[k4][a], fb[k4][b2], acc[a][b2]);
+  };
+  auto stage = [&](int cur, bool do_load, vec_t (&la)[NCHA], vec_t (&lb)[NCHB], bool do_store, vec_t (&sa)[NCHA],
+                   vec_t (&sb)[NCHB], bool has_next) {
+    if (do_load) load_stage(la, lb);
+#pragma unroll
+    for (int k4 = 1; k4 < NK; ++k4) read_frags(cur, k4);
+#pragma unroll
+    for (int k4 = 0; k4 + 2 < NK; ++k4) mfma_step(k4);
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_store) store_stage(cur ^ 1, sa, sb);
+    if (NK >= 2) mfma_step(NK - 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) read_frags(cur ^ 1, 0);
+    mfma_step(NK - 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, TMA + TMB, 0);  // reads first: their latency hides under the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x008, TMA * TMB, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (nstages > 0) {
+    load_stage(ra0, rb0);
+    if (nstages > 1) load_stage(ra1, rb1);
+    store_stage(0, ra0, rb0);
+    __syncthreads();
+    read_frags(0, 0);
+    int s = 0;
+    for (; s + 3 < nstages; s += 2) {
+      stage(0, true, ra0, rb0, true, ra1, rb1, true);
+      stage(1, true, ra1, rb1, true, ra0, rb0, true);
+    }
+    const int left = nstages - s;  // 1..3
+    stage(0, left > 2, ra0, rb0, left > 1, ra1, rb1, left > 1);
+    if (left > 1) stage(1, false, ra1, rb1, left > 2, ra0, rb0, left > 2);
+    if (left > 2) stage(0, false, ra0, rb0, false, ra1, rb1, false);
+  }
+
+  // epilogue: write-through stores (read by other workgroups of this launch)
+  const int er0 = row0 + wm * (TA / G::WM), ec0 = col0 + wn * (TB / G::WN) + (lane & 15);
+  const bool neg = (flags & DAGF_NEG) != 0, accum = (flags & DAGF_ACC) != 0;
+#pragma unroll
+  for (int a = 0; a < TMA; ++a)
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = er0 + a * 16 + C::crow(lane, r);
+        T* p = Cg + (size_t)row * ld + ec0 + b * 16;
+        T v = acc[a][b][r];
+        if (neg) v = -v;
+        if (accum) v += *p;
+        gstore<true>(p, v);
+      }
+}
+
+// bounded wait for one counter; false: give up (another workgroup timed out, or this one did)
+__device__ __forceinline__ bool dag_wait(int* ctrl, int* info, int cnt, int val, int task_idx) {
+  int* c = ctrl + DAG_CTRL_WORDS + cnt;
+  if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= val) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+  unsigned spins = 0;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= val) return true;
+    if ((++spins & 63u) == 0) {
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return false;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        int expected = 0;
+        __hip_atomic_compare_exchange_strong(ctrl + 1, &expected, task_idx + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(info, DAG_INFO_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
+  extern __shared__ __align__(16) char smem_raw[];
+  int* ctl = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);  // [0] task index, [1] 0 run / 1 skip / 2 leave
+  const int t = threadIdx.x;
+  T* W1 = static_cast<T*>(g.W1);
+  T* W2 = static_cast<T*>(g.W2);
+  for (;;) {
+    if (t == 0) {
+      const int idx = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int status = 0;
+      if (idx >= g.ntasks) {
+        status = 2;
+      } else {
+        const DagTask* tk = g.tasks + idx;
+        const int nw = tk->nwait;
+        for (int w = 0; w < nw && status == 0; ++w)
+          if (!dag_wait(g.ctrl, g.info, tk->wcnt[w], tk->wval[w], idx)) status = 2;
+        if (status == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines: operands were written by other CUs
+          const int inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          status = inf < 0 ? 2 : (inf > 0 ? 1 : 0);
+        }
+      }
+      ctl[0] = idx;
+      ctl[1] = status;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the barrier below must not open before the invalidate is complete
+    }
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane(ctl[0]);
+    const int status = __builtin_amdgcn_readfirstlane(ctl[1]);
+    if (status == 2) break;
+    const DagTask tk = g.tasks[idx];
+    if (status == 0) {
+      if (tk.kind == DAG_LEAF) {
+        leaf_body<double, T, true>(W1, W2, g.ld, tk.row0, static_cast<T*>(g.ldiag), g.info, 0, smem_raw);
+      } else if (tk.kind == DAG_GEMM_128x64) {
+        dag_gemm_tile<T, 128, 64>(tk, W1, W2, g.ld, smem_raw);
+      } else {
+        dag_gemm_tile<T, 64, 64>(tk, W1, W2, g.ld, smem_raw);
+      }
+    }
+    // publish: every wave drains its write-through stores, then ONE lane bumps the counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0 && tk.sig != DAG_NOSIG)
+      __hip_atomic_fetch_add(g.ctrl + DAG_CTRL_WORDS + tk.sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <typename T>
+void launch_dag(const DagLaunch& g, int nwg, hipStream_t s) {
+  if (g.ntasks <= 0 || nwg <= 0) return;
+  hipLaunchKernelGGL((dag_kernel<T>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
+}
+template void launch_dag<double>(const DagLaunch&, int, hipStream_t);
+template void launch_dag<float>(const DagLaunch&, int, hipStream_t);
+
+static void init_dag_kernels() {
+  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double>), DAG_LDS_BYTES, "dag_kernel<f64>: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float>), DAG_LDS_BYTES, "dag_kernel<f32>: dynamic LDS limit");
+}

@@ -66,6 +66,46 @@ struct GemmLaunch {
   int sched_nwg;
 };
 
+// ---- device-scheduled factorisation: one persistent launch pulls leaf / tile tasks from an ordered queue ----------
+// (dag_kernel.inc.hpp; plan built on the host by dag_plan.hpp).  A task waits until its counters have reached their
+// values, runs, publishes its results write-through and bumps its own counter.  The queue order is a topological
+// order of the dependency graph, so any number of resident workgroups >= 1 makes progress (no co-residency needed).
+enum : uint16_t { DAG_GEMM_128x64 = 0, DAG_GEMM_64x64 = 1, DAG_LEAF = 2 };
+enum : uint16_t {
+  DAGF_ABUF = 1,   // operand A lives in W2 (else W1)
+  DAGF_BBUF = 2,
+  DAGF_CBUF = 4,
+  DAGF_AKM = 8,    // A tile is read with the contraction index along rows
+  DAGF_BKM = 16,
+  DAGF_NEG = 32,   // alpha = -1
+  DAGF_ACC = 64,   // beta = 1
+};
+constexpr int DAG_MAXWAIT = 4;
+constexpr uint16_t DAG_NOSIG = 0xffff;
+struct DagTask {
+  uint16_t kind, flags;
+  int32_t row0, col0;  // origin of the output tile (elements); leaf: row0 = index of the 128-block
+  int32_t kbeg, kend;  // contraction range (elements, whole stages)
+  uint16_t nwait, sig;
+  uint16_t wcnt[DAG_MAXWAIT];
+  int32_t wval[DAG_MAXWAIT];
+};
+static_assert(sizeof(DagTask) == 48, "DagTask layout");
+constexpr int DAG_CTRL_WORDS = 4;     // ctrl[0] queue head, [1] first task that gave up waiting (+1), [2..3] spare; counters follow
+constexpr int DAG_INFO_TIMEOUT = -2;  // written to EvalOut::info when a wait exceeded its bound (a bug, never a data property)
+struct DagLaunch {
+  const DagTask* tasks;
+  int ntasks;
+  int* ctrl;
+  void* W1;
+  void* W2;
+  int ld;
+  void* ldiag;
+  int* info;
+};
+template <typename T>
+void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);
+
 // ---- launchers (kernels.hip), T in {double, float} ------------------------------------------------------------
 template <typename T>
 void launch_gemm(const GemmLaunch& g, int tile, hipStream_t s);  // tile in {32, 64, 128}

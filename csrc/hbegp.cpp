@@ -30,6 +30,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "dag_plan.hpp"
 #include "engine.hpp"
 #include "lbfgsb.hpp"
 
@@ -160,7 +161,7 @@ static void theta_to_params(const double* theta, const double* lo, const double*
 // ---------------------------------------------------------------------------------------------------------------
 // timing support for hbegp_problem_time_eval
 struct PhaseTimer {
-  enum Kind { KMAT = 0, GEMM = 1, LEAF = 2, LAUUM = 3, ALPHA = 4, GRAD = 5, NKIND = 6 };
+  enum Kind { KMAT = 0, GEMM = 1, LEAF = 2, LAUUM = 3, ALPHA = 4, GRAD = 5, DAG = 6, NKIND = 7 };
   struct Rec {
     hipEvent_t a, b;
     int kind, tile;
@@ -291,6 +292,7 @@ struct Slot {
   double *part_t = nullptr, *part_g = nullptr;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
+  int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
   EvalOut* hOut = nullptr;   // pinned
   hipGraphExec_t graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [target][want_grad]
@@ -320,6 +322,12 @@ struct Problem : ProblemBase {
   std::vector<T*> Xd, yd;                 // per device
   std::vector<std::vector<Slot<T>>> slots;  // [device][slot]
   std::vector<std::vector<Sched>> scheds;   // [device][gemm launch ordinal]
+  // device-scheduled factorisation (dag_kernel.inc.hpp): one plan per problem, the same on every device
+  bool dag_ = false;
+  std::vector<DagTask*> dag_tasks;          // per device
+  int dag_ntasks = 0, dag_nwg = 0;
+  size_t dag_ctrl_bytes = 0;
+  double dag_gflop = 0;
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
 
@@ -380,6 +388,36 @@ struct Problem : ProblemBase {
       }
       HIPCHECK(hipDeviceSynchronize());
     }
+    // Task queue of the factorisation.  The workgroups of one launch hold a CU each while they wait for the diagonal
+    // blocks, so a problem whose slots run concurrently shares the CUs between its slots.
+    const int dag_env = env_int("HBEGP_DAG", 1);  // read per problem: the parity tests flip it inside one process
+    dag_ = dag_env != 0 && !adhoc_ && np / NB >= 2;
+    if (dag_) {
+      DagBuilder builder(is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 2));
+      DagPlan plan = builder.build(0, np / NB);
+      if (env_int("HBEGP_DAG_VALIDATE", 0)) {
+        const std::string why = dag_plan_validate(plan, np / NB);
+        if (!why.empty()) throw std::runtime_error("task queue of the factorisation is unsound: " + why);
+      }
+      dag_ntasks = (int)plan.tasks.size();
+      dag_gflop = plan.gflop;
+      dag_ctrl_bytes = (sizeof(int) * (DAG_CTRL_WORDS + plan.totals.size()) + 15) / 16 * 16;
+      dag_tasks.assign(c->devs.size(), nullptr);
+      for (size_t di = 0; di < c->devs.size(); ++di) {
+        HIPCHECK(hipSetDevice(c->devs[di]));
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, c->devs[di]));
+        const int forced = env_int("HBEGP_DAG_WG", 0);
+        dag_nwg = forced > 0 ? forced : std::max(1, prop.multiProcessorCount / std::max(1, n_slots));
+        dag_nwg = std::min(dag_nwg, dag_ntasks);
+        HIPCHECK(hipMalloc(&dag_tasks[di], sizeof(DagTask) * plan.tasks.size()));
+        HIPCHECK(hipMemcpy(dag_tasks[di], plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
+        for (auto& s : slots[di]) {
+          HIPCHECK(hipMalloc(&s.dag_ctrl, dag_ctrl_bytes));
+          HIPCHECK(hipMemset(s.dag_ctrl, 0, dag_ctrl_bytes));
+        }
+      }
+    }
     // build the static GEMM schedules (per device; shared by its slots) by walking one evaluation without launching
     scheds.resize(c->devs.size());
     if (adhoc_) return;
@@ -404,16 +442,18 @@ struct Problem : ProblemBase {
         g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb);
         for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
         (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
-        (void)hipFree(s.dP); (void)hipFree(s.dOut);
+        (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl);
         (void)hipHostFree(s.hP); (void)hipHostFree(s.hOut);
         if (s.stream) (void)hipStreamDestroy(s.stream);
       }
       (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
+      if (di < dag_tasks.size()) (void)hipFree(dag_tasks[di]);
       if (di < scheds.size())
         for (auto& sc : scheds[di]) { (void)hipFree(sc.d_off); (void)hipFree(sc.d_items); }
     }
     slots.clear();
     scheds.clear();
+    dag_tasks.clear();
     Xd.clear();
     yd.clear();
   }
@@ -533,6 +573,18 @@ struct Problem : ProblemBase {
   // covering everything below / behind it) and the off-diagonal blocks of X = L^-1 are formed afterwards level by level,
   // all nodes of a level in one launch (they are independent: TRTRI has no dependency along the diagonal).
   void chol_inv(Slot<T>& s, size_t di, int nb, PhaseTimer* tm) {
+    if (dag_ && !adhoc_) {
+      // the whole recursion in ONE persistent launch: workgroups pull diagonal-block and tile tasks from an ordered queue
+      if (dry_) return;
+      HIPCHECK(hipMemsetAsync(s.dag_ctrl, 0, dag_ctrl_bytes, s.stream));
+      DagLaunch g{};
+      g.tasks = dag_tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
+      g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
+      if (tm) tm->begin(PhaseTimer::DAG, 0, dag_gflop);
+      launch_dag<T>(g, dag_nwg, s.stream);
+      if (tm) tm->end();
+      return;
+    }
     static const int big_env = env_int("HBEGP_NBIG", 1 << 20);  // measured at n=4096: 8 -> 3.55 ms, 4 -> 3.56, off (binary recursion only) -> 3.43
     const int big = std::max(1, big_env);
     const int nbb = (nb + big - 1) / big;
@@ -651,6 +703,7 @@ struct Problem : ProblemBase {
     CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
     HIPCHECK(hipStreamSynchronize(s.stream));
+    if (s.hOut->info < 0) throw HipError{hipErrorLaunchTimeOut, "factorisation task queue: a dependency wait exceeded its bound", __LINE__};
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
   }
 
@@ -753,6 +806,7 @@ struct Problem : ProblemBase {
     HIPCHECK(hipStreamSynchronize(s.stream));
     s.last_target = target;
     const int p = d + 2;
+    if (s.hOut->info < 0) throw HipError{hipErrorLaunchTimeOut, "factorisation task queue: a dependency wait exceeded its bound", __LINE__};
     if (s.hOut->info != 0) {
       *lml = -std::numeric_limits<double>::infinity();
       if (grad) for (int j = 0; j < p; ++j) grad[j] = 0.0;  // fit.rs:105-112
@@ -797,7 +851,7 @@ struct Problem : ProblemBase {
     float ms = 0;
     HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
     if (phase_ms) {
-      for (int i = 0; i < 20; ++i) phase_ms[i] = 0;
+      for (int i = 0; i < 24; ++i) phase_ms[i] = 0;
       phase_ms[6] = ms / reps;
       // eager pass with one event pair per launch
       const int treps = std::max(1, std::min(reps, 3));
@@ -828,6 +882,7 @@ struct Problem : ProblemBase {
           if (rec.kind == PhaseTimer::LAUUM) phase_ms[3] += v;
           if (rec.kind == PhaseTimer::ALPHA) phase_ms[4] += v;
           if (rec.kind == PhaseTimer::GRAD) phase_ms[5] += v;
+          if (rec.kind == PhaseTimer::DAG) { phase_ms[19] += v; phase_ms[20] += rec.gflop / treps; }
           if (rec.kind == PhaseTimer::GEMM || rec.kind == PhaseTimer::LAUUM) {
             const int o = rec.tile == 128 ? 8 : (rec.tile == 64 ? 10 : 12);
             phase_ms[o] += v;
@@ -1457,6 +1512,22 @@ void hbegp_model_retain(hbegp_model* model) {
 }
 void hbegp_model_release(hbegp_model* model) {
   if (model && model->refs.fetch_sub(1) == 1) delete model;
+}
+
+int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int* ntasks, int* ncounters, int* nleaf, double* gflop, char* err,
+                         int errlen) {
+  if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0) return fail(HBEGP_EINVAL, "bad argument");
+  GUARD_BEGIN
+  DagBuilder builder(bk, small_h);
+  const DagPlan plan = builder.build(0, nblocks);
+  const std::string why = dag_plan_validate(plan, nblocks);
+  if (ntasks) *ntasks = (int)plan.tasks.size();
+  if (ncounters) *ncounters = (int)plan.totals.size();
+  if (nleaf) *nleaf = plan.n_leaf;
+  if (gflop) *gflop = plan.gflop;
+  if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", why.c_str());
+  return why.empty() ? HBEGP_OK : fail(HBEGP_EINVAL, "%s", why.c_str());
+  GUARD_END
 }
 
 double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, const double* lo, const double* hi, int n,

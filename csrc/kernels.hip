@@ -481,17 +481,23 @@ __device__ long long g_leaf_stamps[64];
 #define LEAF_STAMP(i) do { if ((dbg & 8) && t == 0) g_leaf_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
 void read_leaf_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_leaf_stamps), sizeof(long long) * 64); }
 
-template <typename T, typename TIO>
-__global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
-                                                   TIO* __restrict__ ldiag, int* info, int dbg) {
+// Results another workgroup of the SAME launch will read (the task-queue kernel, dag_kernel.inc.hpp) are stored
+// write-through (sc1) so that they need no release fence; between launches plain stores do.
+template <bool SC1, typename TIO>
+__device__ __forceinline__ void gstore(TIO* p, TIO v) {
+  if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <typename T, typename TIO, bool SC1>
+__device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
+                                          TIO* __restrict__ ldiag, int* info, int dbg, char* smem_raw) {
   using C = Cfg<T>;
   using L = LeafGeom<T>;
   using acc_t = typename C::acc_t;
   using vec_t = typename Cfg<TIO>::vec_t;
   constexpr int S = L::S, YS = L::YS, YB = L::YB, VEC = Cfg<TIO>::VEC;
-  if (*info != 0) return;
 
-  extern __shared__ __align__(16) char smem_raw[];
   T* As = reinterpret_cast<T*>(smem_raw);  // [128][S]: lower = A -> L ; strict upper blocks = X^T
   T* Ys = As + 128 * S;                    // [8][16][YS]: inverses of the diagonal 16x16 factors
   T* Sc = Ys + 8 * YB;                     // [4][16][YS]: per-wave scratch
@@ -580,7 +586,7 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
       const int row = C::crow(lane, r);
       const T v = -res[r];
       As[(j * 16 + m16) * S + i * 16 + row] = v;             // transposed copy for later products
-      Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16] = (TIO)v;  // X[i,j]
+      gstore<SC1>(&Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16], (TIO)v);  // X[i,j]
     }
   };
 
@@ -697,8 +703,16 @@ __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO*
   // diagonal sub-blocks of X
   for (int c = t; c < 8 * 256; c += 512) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
-    Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j] = (TIO)Ys[pblk * YB + r * YS + j];
+    gstore<SC1>(&Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j], (TIO)Ys[pblk * YB + r * YS + j]);
   }
+}
+
+template <typename T, typename TIO>
+__global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
+                                                   TIO* __restrict__ ldiag, int* info, int dbg) {
+  if (*info != 0) return;
+  extern __shared__ __align__(16) char smem_raw[];
+  leaf_body<T, TIO, false>(W1, W2, ld, blk, ldiag, info, dbg, smem_raw);
 }
 
 template <typename T>
@@ -1233,6 +1247,7 @@ template void launch_pred_var<float>(const float*, const float*, int, int, const
 
 // Per-device one-time setup: kernels that use more than 64 KiB of dynamic LDS need the attribute raised.  Called from
 // hbegp_ctx_create() for every device, before any stream capture.
+static void init_dag_kernels();  // dag_kernel.inc.hpp (end of this file)
 static void set_lds_attr(const void* fn, int bytes, const char* what) {
   const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -1247,6 +1262,7 @@ void init_kernels() {
   init_gemm_attr<float, 128>(); init_gemm_attr<float, 64>(); init_gemm_attr<float, 32>();
   set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, double>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f64>: dynamic LDS limit");
   set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, float>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f32>: dynamic LDS limit");
+  init_dag_kernels();
 }
 
 __global__ void set_info_kernel(int* info, int value) { *info = value; }
@@ -1262,5 +1278,7 @@ __global__ void reset_out_kernel(EvalOut* out) {
   if (t < MAXP) out->grad[t] = nan;
 }
 void launch_reset_out(EvalOut* out, hipStream_t s) { hipLaunchKernelGGL(reset_out_kernel, dim3(1), dim3(128), 0, s, out); }
+
+#include "dag_kernel.inc.hpp"
 
 }  // namespace hbegp

@@ -127,11 +127,11 @@ class Problem:
     def time_eval(self, theta, reps=5, dev=0, slot=0):
         lib = _lib.load()
         theta = _lib.as_c(theta, np.float64)
-        phases = np.zeros(20)
+        phases = np.zeros(24)
         _lib.check(lib.hbegp_problem_time_eval(self._h, dev, slot, _lib.dptr(theta), reps, _lib.dptr(phases)))
         keys = ["kmat_ms", "chol_gemm_ms", "leaf_ms", "lauum_ms", "alpha_ms", "gradtrace_ms", "eval_graph_ms", "n_gemm",
                 "gemm128_ms", "gemm128_gflop", "gemm64_ms", "gemm64_gflop", "gemm32_ms", "gemm32_gflop", "eval_eager_ms", "n_leaf",
-                "n_gemm128", "n_gemm64", "n_gemm32", "reserved"]
+                "n_gemm128", "n_gemm64", "n_gemm32", "dag_ms", "dag_gflop", "r1", "r2", "r3"]
         return dict(zip(keys, phases.tolist()))
 
 

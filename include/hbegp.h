@@ -89,7 +89,8 @@ int hbegp_problem_kmat_f32(hbegp_problem* prob, int dev, int slot, const double*
  * [0] kmat, [1] chol+trtri GEMM launches (sum), [2] leaf (diag-block) launches (sum), [3] lauum GEMM,
  * [4] alpha/lml reductions, [5] gradtrace, [6] whole evaluation (graph replay), [7] number of GEMM launches/eval,
  * [8..13] (ms, algorithmic GFLOP) of the 128-, 64- and 32-tile GEMM launches, [14] eager evaluation, [15] leaf launches,
- * [16..18] launches per evaluation of the 128-, 64-, 32-tile GEMM.  phase_ms must have room for 20 doubles. */
+ * [16..18] launches per evaluation of the 128-, 64-, 32-tile GEMM, [19] the factorisation's task-queue launch (ms),
+ * [20] its algorithmic GFLOP.  phase_ms must have room for 24 doubles. */
 int hbegp_problem_time_eval(hbegp_problem* prob, int dev, int slot, const double* theta, int reps,
                             double* phase_ms);
 
@@ -159,6 +160,13 @@ typedef double (*hbegp_objective_fn)(const double* x, double* grad, void* user);
 /* Bounded L-BFGS minimisation; x is updated in place; returns the best objective value found. */
 double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, const double* lo, const double* hi,
                                   int n, int maxeval);
+
+/* ---- test hook (host only, no GPU): build the task queue of the device-scheduled factorisation for `nblocks`
+ * 128-blocks (bk = contraction elements per stage: 16 for f64, 32 for f32; nodes up to small_h blocks wide use 64x64
+ * tiles) and check it: queue order topological (=> deadlock-free for any number of resident workgroups), every wait
+ * for a full count, no unordered access to a tile.  Returns HBEGP_OK or HBEGP_EINVAL with the reason in err. */
+int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int* ntasks, int* ncounters, int* nleaf, double* gflop,
+                         char* err, int errlen);
 
 #ifdef __cplusplus
 }
