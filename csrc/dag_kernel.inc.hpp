@@ -39,11 +39,12 @@ struct DagGeom {
 };
 
 constexpr int DAG_LDS_CTL_OFF = (int)((LeafGeom<double>::LDS_BYTES + 15) / 16 * 16);
-constexpr int DAG_LDS_BYTES = DAG_LDS_CTL_OFF + 64;
+constexpr int DAG_LDS_BYTES = DAG_LDS_CTL_OFF + 128;
 static_assert(DAG_LDS_BYTES <= 163840, "the diagonal block and the control words must fit the CU's LDS");
 
 template <typename T, int TA, int TB>
-__device__ __forceinline__ void dag_gemm_tile(const DagTask& tk, T* __restrict__ W1, T* __restrict__ W2, int ld, char* smem_raw) {
+__device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int kbeg, int kend, T* __restrict__ W1,
+                                              T* __restrict__ W2, int ld, char* smem_raw) {
   using C = Cfg<T>;
   using G = DagGeom<T, TA, TB>;
   using vec_t = typename C::vec_t;
@@ -51,13 +52,11 @@ __device__ __forceinline__ void dag_gemm_tile(const DagTask& tk, T* __restrict__
   constexpr int VEC = C::VEC, BK = G::BK, SK = G::SK, SMA = G::SMA, SMB = G::SMB, NCHA = G::NCHA, NCHB = G::NCHB;
   constexpr int TMA = G::TMA, TMB = G::TMB, NT = G::NT;
 
-  const int flags = tk.flags;
   const int akm = (flags & DAGF_AKM) ? 1 : 0, bkm = (flags & DAGF_BKM) ? 1 : 0;
   const T* Ag = (flags & DAGF_ABUF) ? W2 : W1;
   const T* Bg = (flags & DAGF_BBUF) ? W2 : W1;
   T* Cg = (flags & DAGF_CBUF) ? W2 : W1;
-  const int row0 = tk.row0, col0 = tk.col0, kbeg = tk.kbeg;
-  const int nstages = (tk.kend - tk.kbeg) / BK;
+  const int nstages = (kend - kbeg) / BK;
 
   T* lds = reinterpret_cast<T*>(smem_raw);  // [A buf0 | A buf1 | B buf0 | B buf1]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -202,50 +201,77 @@ __device__ __forceinline__ bool dag_wait(int* ctrl, int* info, int cnt, int val,
 template <typename T>
 __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
   extern __shared__ __align__(16) char smem_raw[];
-  int* ctl = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);  // [0] task index, [1] 0 run / 1 skip / 2 leave
+  int* ctl = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);  // [0] task index, [1] 0 run / 1 skip / 2 leave, [4..15] the task
   const int t = threadIdx.x;
   T* W1 = static_cast<T*>(g.W1);
   T* W2 = static_cast<T*>(g.W2);
+  constexpr int TASK_DW = (int)(sizeof(DagTask) / 4);
+  int next = 0;  // thread 0: index of the task pulled for the next round
+  if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (;;) {
-    if (t == 0) {
-      const int idx = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int status = 0;
-      if (idx >= g.ntasks) {
-        status = 2;
-      } else {
-        const DagTask* tk = g.tasks + idx;
-        const int nw = tk->nwait;
-        for (int w = 0; w < nw && status == 0; ++w)
-          if (!dag_wait(g.ctrl, g.info, tk->wcnt[w], tk->wval[w], idx)) status = 2;
-        if (status == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines: operands were written by other CUs
-          const int inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          status = inf < 0 ? 2 : (inf > 0 ? 1 : 0);
+    if (t < 64) {
+      // wave 0: stage the task descriptor in LDS (one load instruction), then lane 0 waits for its dependencies
+      const int idx = __builtin_amdgcn_readfirstlane(next);
+      int status = idx >= g.ntasks ? 2 : 0;
+      if (g.trace && t == 0 && status == 0) g.trace[(size_t)idx * 5 + 0] = __builtin_amdgcn_s_memrealtime();
+      if (status == 0) {
+        if (t < TASK_DW) ctl[4 + t] = reinterpret_cast<const int*>(g.tasks + idx)[t];
+        if (t == 0) {
+          const DagTask* tk = reinterpret_cast<const DagTask*>(ctl + 4);  // same wave: LDS accesses are in order
+          const int nw = tk->nwait;
+          for (int w = 0; w < nw && status == 0; ++w)
+            if (!dag_wait(g.ctrl, g.info, tk->wcnt[w], tk->wval[w], idx)) status = 2;
+          if (status == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines: operands were written by other CUs
+            const int inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            status = inf < 0 ? 2 : (inf > 0 ? 1 : 0);
+          }
         }
       }
-      ctl[0] = idx;
-      ctl[1] = status;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the barrier below must not open before the invalidate is complete
-    }
-    __syncthreads();
-    const int idx = __builtin_amdgcn_readfirstlane(ctl[0]);
-    const int status = __builtin_amdgcn_readfirstlane(ctl[1]);
-    if (status == 2) break;
-    const DagTask tk = g.tasks[idx];
-    if (status == 0) {
-      if (tk.kind == DAG_LEAF) {
-        leaf_body<double, T, true>(W1, W2, g.ld, tk.row0, static_cast<T*>(g.ldiag), g.info, 0, smem_raw);
-      } else if (tk.kind == DAG_GEMM_128x64) {
-        dag_gemm_tile<T, 128, 64>(tk, W1, W2, g.ld, smem_raw);
-      } else {
-        dag_gemm_tile<T, 64, 64>(tk, W1, W2, g.ld, smem_raw);
+      if (t == 0) {
+        ctl[0] = idx;
+        ctl[1] = status;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the barrier below must not open before the invalidate is complete
+        if (g.trace && status != 2) g.trace[(size_t)idx * 5 + 1] = __builtin_amdgcn_s_memrealtime();
       }
     }
-    // publish: every wave drains its write-through stores, then ONE lane bumps the counter
+    __syncthreads();
+    const int status = __builtin_amdgcn_readfirstlane(ctl[1]);
+    if (status == 2) break;
+    // the task, as uniform (scalar) values: dword layout of DagTask
+    const int kf = __builtin_amdgcn_readfirstlane(ctl[4]);
+    const int kind = kf & 0xffff, flags = (kf >> 16) & 0xffff;
+    const int row0 = __builtin_amdgcn_readfirstlane(ctl[5]), col0 = __builtin_amdgcn_readfirstlane(ctl[6]);
+    const int kbeg = __builtin_amdgcn_readfirstlane(ctl[7]), kend = __builtin_amdgcn_readfirstlane(ctl[8]);
+    const int sig0 = (__builtin_amdgcn_readfirstlane(ctl[9]) >> 16) & 0xffff, sig1 = __builtin_amdgcn_readfirstlane(ctl[10]) & 0xffff;
+    if (status == 0) {
+      if (kind == DAG_LEAF) {
+        leaf_body<double, T, true>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, 0, smem_raw);
+      } else if (kind == DAG_GEMM_128x64) {
+        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
+      } else {
+        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
+      }
+    }
+    const int cur_idx = __builtin_amdgcn_readfirstlane(ctl[0]);
+    if (g.trace && t == 0) g.trace[(size_t)cur_idx * 5 + 2] = __builtin_amdgcn_s_memrealtime();
+    // pull the next task while this one's stores drain (the workgroup still runs its tasks in queue order)
+    if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // publish: every wave drains its write-through stores, then lanes of ONE wave bump the counters
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0 && tk.sig != DAG_NOSIG)
-      __hip_atomic_fetch_add(g.ctrl + DAG_CTRL_WORDS + tk.sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      const int mysig = t == 0 ? sig0 : sig1;
+      if (t < DAG_MAXSIG && mysig != DAG_NOSIG)
+        __hip_atomic_fetch_add(g.ctrl + DAG_CTRL_WORDS + mysig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g.trace && t == 0) {
+        g.trace[(size_t)cur_idx * 5 + 3] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g.trace[(size_t)cur_idx * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+      }
+    }
   }
 }
 

@@ -3,19 +3,32 @@
 // Plain C++ (no HIP): also compiled into the CPU-only tests through hbegp_debug_dag_plan().
 //
 // Recursion (same as Problem::chol_inv_rec / chol_inv_split, lml.rs:47 + the inverse of the factor lml.rs:62 needs):
-//   node [lo, hi), mid:   left subtree;  T = A21 X11^T (W1,W2 -> W2[2,1]);  A22 -= T T^T (W2 -> W1, lower);
-//                         U = T X11 (W2 -> W1[2,1]);  right subtree;  X21 = -X22 U (W2,W1 -> W2[2,1])
-// Counters: one per product and one per diagonal block.  Every wait is for the FULL count of a counter, so "B waits on
-// c" means "every task that bumps c happened before B" -- which is what dag_plan_validate() relies on.
-//   T      waits: left subtree complete            (its X11, and through it every earlier update of A21)
-//   SYRK,U wait : all T tiles                      (U overwrites A21, which every T tile of its row has read)
-//   right subtree's diagonal blocks wait: all SYRK tiles of this node (their gate; inner nodes inherit it through
-//                                         the chain leaf -> T -> ...)
-//   X21    waits: right subtree complete, all U tiles   (it overwrites T: SYRK and U have read it)
+//   node N = [lo, hi), mid:   left subtree L;  T = A21 X11^T (W1,W2 -> W2[2,1]);  A22 -= T T^T (W2 -> W1, lower);
+//                             U = T X11 (W2 -> W1[2,1]);  right subtree R;  X21 = -X22 U (W2,W1 -> W2[2,1])
+// Dependencies are per 128-row block, so that the latency-bound chain of diagonal blocks runs ahead of (and beside) the
+// bulk tiles -- the launch-per-product path can only run them one after the other.  Every wait is for the FULL count of a
+// counter ("B waits on c" = "every task that bumps c happened before B"), which is what dag_plan_validate() relies on.
+//   counters   leaf[k] | Trow[N][i] | Srow[N][i], Sall[N] | Uall[N] | Xrow[N][i], Xall[N]
+//   rowfinal(S, j)  "row block j of X = L^-1 is final inside subtree S": Xrow[M][j] of the highest node M in S with j in
+//                   its right half, or leaf[j] when j is S's first block
+//   gate(i)         "row block i of the Schur complement is up to date": Srow[P][i] of the nearest ancestor P whose right
+//                   half holds i (none for rows no ancestor updates)
+//   leaf(k)        waits gate(k)
+//   T(N)(i,j)      waits rowfinal(L, j) [X11 row j], gate(i) [A21 row i]                      bumps Trow[N][i]
+//   SYRK(N)(i,j)   waits Trow[N][i], Trow[N][j]                                               bumps Srow[N][i], Sall[N]
+//   U(N)(i,j)      waits Trow[N][i]  (whole rows of T imply all of X11; U overwrites A21(i,j), read by T's row i)
+//                                                                                            bumps Uall[N]
+//   X21(N)(i,j)    waits rowfinal(R, i) [X22 row i], Uall[N], Sall[N] (it overwrites T(i,j), read by SYRK and U)
+//                                                                                            bumps Xrow[N][i], Xall[N]
+// Queue order: a list schedule simulated on the host for the number of workgroups the launch will have (critical-path
+// priority, estimated task times); workgroups pull in that order, so tasks tend to be pulled when their inputs are ready.
+// Any topological order is deadlock-free for any number of resident workgroups; this one is also fast.
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -28,42 +41,67 @@ struct DagPlan {
   std::vector<int> totals;  // per counter: number of tasks that bump it
   double gflop = 0;         // algorithmic flops of the tile products (2*128^3 per pair of 128-blocks, half on triangles)
   int n_leaf = 0;
+  double sim_us = 0;        // makespan of the simulated schedule (estimate)
+  double crit_us = 0;       // critical path of the graph under the same estimates
 };
 
 struct DagGate {
   int cnt = -1, val = 0;  // cnt < 0: nothing to wait for
 };
 
+// estimated task times in microseconds (MI355X, one workgroup of 512 threads per CU; measured round 2)
+struct DagCosts {
+  // from task traces (tools/dag_trace.py, n=4096 f64): diagonal block 28.3 us; tile = 1.5 us + 3.9 (64x64) / 7.9 (128x64) us
+  // per 128 elements of contraction (81-84 % of one CU's fp64 MFMA peak); counter bump -> dependent task running ~4 us
+  double leaf = 28.5 + 4.0;
+  double overhead = 1.5 + 4.0;
+  double per128_big = 7.9;
+  double per128_small = 3.9;
+};
+
 class DagBuilder {
  public:
   // bk: contraction elements per pipeline stage (16 for f64, 32 for f32): ranges are whole stages
   // small_h: nodes whose halves are at most this many 128-blocks wide use 64x64 tiles (latency-bound products)
-  DagBuilder(int bk, int small_h) : bk_(bk), small_h_(small_h) {}
+  // nwg: workgroups the queue is ordered for (0: keep the recursion's order)
+  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true) : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine) {}
 
   DagPlan build(int blo, int bhi) {
     plan_ = DagPlan();
-    rec(blo, bhi, DagGate());
+    rec(blo, bhi, nullptr);
+    if (plan_.totals.size() >= 0xffff) plan_.tasks.clear();  // counter ids are 16-bit: the caller falls back
+    for (int tot : plan_.totals)
+      if (tot > 0xffff) plan_.tasks.clear();
+    if (nwg_ > 0 && !plan_.tasks.empty()) order();
     return plan_;
   }
 
  private:
-  int bk_, small_h_;
+  int bk_, small_h_, nwg_;
+  bool fine_;
   DagPlan plan_;
+  DagCosts cost_;
 
   int new_counter() {
     plan_.totals.push_back(0);
     return (int)plan_.totals.size() - 1;
   }
-  void push(DagTask t, const std::vector<DagGate>& waits, int sig) {
+  void push(DagTask t, const std::vector<DagGate>& waits, int sig0, int sig1, double cost_us) {
     t.nwait = 0;
-    for (const DagGate& g : waits)
-      if (g.cnt >= 0) {
-        t.wcnt[t.nwait] = (uint16_t)g.cnt;
-        t.wval[t.nwait] = g.val;
-        ++t.nwait;
-      }
-    t.sig = sig < 0 ? DAG_NOSIG : (uint16_t)sig;
-    if (sig >= 0) plan_.totals[sig]++;
+    for (const DagGate& g : waits) {
+      if (g.cnt < 0) continue;
+      bool dup = false;
+      for (int w = 0; w < t.nwait; ++w) dup = dup || t.wcnt[w] == g.cnt;
+      if (dup) continue;
+      t.wcnt[t.nwait] = (uint16_t)g.cnt;
+      t.wval[t.nwait] = (uint16_t)g.val;
+      ++t.nwait;
+    }
+    t.sig[0] = sig0 < 0 ? DAG_NOSIG : (uint16_t)sig0;
+    t.sig[1] = sig1 < 0 ? DAG_NOSIG : (uint16_t)sig1;
+    if (sig0 >= 0) plan_.totals[sig0]++;
+    if (sig1 >= 0) plan_.totals[sig1]++;
+    t.cost = (uint16_t)std::min(65535.0, cost_us * 10.0);
     plan_.tasks.push_back(t);
   }
 
@@ -75,12 +113,13 @@ class DagBuilder {
     int klim;            // 0 none | 1: k <= tj | 2: k >= tj | 3: k <= ti   (64-element units, as gemm_kernel's 64-tile)
     bool tri_a, tri_b;   // operand is triangular (flop accounting only)
   };
+  struct Tile { int kind, bi, bj, row0, col0, ka, kb; };
 
-  // emit the tiles of one product; returns the number of tasks.  order: deepest contraction first.
-  int emit(const Op& op, bool small, const std::vector<DagGate>& waits, int sig) {
-    struct Tile { int kind, row0, col0, ka, kb; };
+  // the tiles of one product, block row by block row (deepest contraction first inside a row)
+  std::vector<Tile> tiles_of(const Op& op, bool small) {
     std::vector<Tile> tiles;
-    for (int bi = op.r0; bi < op.r1; ++bi)
+    for (int bi = op.r0; bi < op.r1; ++bi) {
+      const size_t row_begin = tiles.size();
       for (int bj = op.c0; bj < op.c1; ++bj) {
         if (op.lower && bj > bi) continue;
         const bool diag = op.lower && bi == bj;
@@ -98,85 +137,206 @@ class DagBuilder {
               if (diag && ti < tj) continue;  // strictly upper 64-tile of a symmetric result
               int ka, kb;
               krange(ti, &ka, &kb);
-              tiles.push_back({DAG_GEMM_64x64, ti * 64, tj * 64, ka * 64, kb * 64});
+              tiles.push_back({DAG_GEMM_64x64, bi, bj, ti * 64, tj * 64, ka * 64, kb * 64});
             }
           } else {
             int ka, kb;
             krange(2 * bi + 1, &ka, &kb);  // the tile's lower 64 rows decide; the extra range of the upper rows meets zeros
-            tiles.push_back({DAG_GEMM_128x64, bi * 128, tj * 64, ka * 64, kb * 64});
+            tiles.push_back({DAG_GEMM_128x64, bi, bj, bi * 128, tj * 64, ka * 64, kb * 64});
           }
         }
         // flops, as Problem::op_gflop counts them
-        {
-          int ka = op.k0, kb = op.k1;
-          if (op.klim == 1) kb = std::min(kb, bj + 1);
-          if (op.klim == 2) ka = std::max(ka, bj);
-          if (op.klim == 3) kb = std::min(kb, bi + 1);
-          for (int k = ka; k < kb; ++k) {
-            double w = 1.0;
-            if ((op.tri_a && k == bi) || (op.tri_b && k == bj)) w = 0.5;
-            if (op.lower && bi == bj) w = std::min(w, 0.5);
-            plan_.gflop += w * 2.0 * 128.0 * 128.0 * 128.0 * 1e-9;
-          }
+        int ka = op.k0, kb = op.k1;
+        if (op.klim == 1) kb = std::min(kb, bj + 1);
+        if (op.klim == 2) ka = std::max(ka, bj);
+        if (op.klim == 3) kb = std::min(kb, bi + 1);
+        for (int k = ka; k < kb; ++k) {
+          double w = 1.0;
+          if ((op.tri_a && k == bi) || (op.tri_b && k == bj)) w = 0.5;
+          if (op.lower && bi == bj) w = std::min(w, 0.5);
+          plan_.gflop += w * 2.0 * 128.0 * 128.0 * 128.0 * 1e-9;
         }
       }
-    std::stable_sort(tiles.begin(), tiles.end(), [](const Tile& a, const Tile& b) {
-      const long wa = (long)(a.kb - a.ka) * (a.kind == DAG_GEMM_128x64 ? 2 : 1), wb = (long)(b.kb - b.ka) * (b.kind == DAG_GEMM_128x64 ? 2 : 1);
-      return wa > wb;
-    });
-    for (const Tile& tl : tiles) {
-      DagTask t{};
-      t.kind = (uint16_t)tl.kind;
-      t.flags = op.flags;
-      t.row0 = tl.row0; t.col0 = tl.col0;
-      t.kbeg = tl.ka / bk_ * bk_;
-      t.kend = (tl.kb + bk_ - 1) / bk_ * bk_;
-      push(t, waits, sig);
+      std::stable_sort(tiles.begin() + row_begin, tiles.end(), [](const Tile& a, const Tile& b) {
+        const long wa = (long)(a.kb - a.ka) * (a.kind == DAG_GEMM_128x64 ? 2 : 1), wb = (long)(b.kb - b.ka) * (b.kind == DAG_GEMM_128x64 ? 2 : 1);
+        return wa > wb;
+      });
     }
-    return (int)tiles.size();
+    return tiles;
+  }
+  DagTask make(const Op& op, const Tile& tl, double* cost_us) {
+    DagTask t{};
+    t.kind = (uint16_t)tl.kind;
+    t.flags = op.flags;
+    t.row0 = tl.row0; t.col0 = tl.col0;
+    t.kbeg = tl.ka / bk_ * bk_;
+    t.kend = (tl.kb + bk_ - 1) / bk_ * bk_;
+    *cost_us = cost_.overhead + (t.kend - t.kbeg) / 128.0 * (tl.kind == DAG_GEMM_128x64 ? cost_.per128_big : cost_.per128_small);
+    return t;
+  }
+  static int count_row(const std::vector<Tile>& tiles, int bi) {
+    int c = 0;
+    for (const Tile& t : tiles) c += t.bi == bi;
+    return c;
   }
 
-  // returns the gate "X of [lo, hi) is final"
-  DagGate rec(int lo, int hi, DagGate gate) {
+  struct Sub {
+    int lo = 0, hi = 0;
+    std::vector<DagGate> rowfin;  // [j - lo]: row block j of X is final inside this subtree
+    DagGate all;                  // the whole subtree is final
+  };
+  typedef std::vector<DagGate> RowGates;  // indexed by absolute block row; cnt < 0 where nothing has to be waited for
+
+  Sub rec(int lo, int hi, const RowGates* gate) {
+    Sub out;
+    out.lo = lo; out.hi = hi;
+    auto gate_of = [&](int i) { return (gate && i < (int)gate->size()) ? (*gate)[i] : DagGate(); };
     if (hi - lo == 1) {
       DagTask t{};
       t.kind = DAG_LEAF;
       t.row0 = lo;
       const int c = new_counter();
-      push(t, {gate}, c);
+      push(t, {gate_of(lo)}, c, -1, cost_.leaf);
       plan_.n_leaf++;
-      return DagGate{c, 1};
+      out.rowfin.assign(1, DagGate{c, 1});
+      out.all = DagGate{c, 1};
+      return out;
     }
     const int mid = lo + (hi - lo) / 2;
     const bool small = std::max(mid - lo, hi - mid) <= small_h_;
-    const DagGate left = rec(lo, mid, gate);
-    // T = A21 * X11^T -> W2[2,1]
-    const int cT = new_counter();
+    const Sub left = rec(lo, mid, gate);
+    double cu = 0;
+    // ---- T = A21 * X11^T -> W2[2,1]
     Op t{};
     t.flags = DAGF_BBUF | DAGF_CBUF;  // A = W1, B = W2, C = W2
     t.r0 = mid; t.r1 = hi; t.c0 = lo; t.c1 = mid; t.k0 = lo; t.k1 = mid; t.klim = 1; t.tri_b = true;
-    const int nT = emit(t, small, {left}, cT);
-    const DagGate gT{cT, nT};
-    // A22 -= T T^T (lower) -> W1: gates the right subtree, so it is queued before U
-    const int cS = new_counter();
+    const std::vector<Tile> tt = tiles_of(t, small);
+    RowGates trow(hi);
+    for (int i = mid; i < hi; ++i) trow[i] = DagGate{new_counter(), count_row(tt, i)};
+    for (const Tile& tl : tt) {
+      const DagTask tk = make(t, tl, &cu);
+      push(tk, {fine_ ? left.rowfin[tl.bj - lo] : left.all, gate_of(tl.bi)}, trow[tl.bi].cnt, -1, cu);
+    }
+    // ---- A22 -= T T^T (lower) -> W1: its rows gate the right subtree
     Op s{};
     s.flags = DAGF_ABUF | DAGF_BBUF | DAGF_NEG | DAGF_ACC;  // A = B = W2, C = W1
     s.r0 = mid; s.r1 = hi; s.c0 = mid; s.c1 = hi; s.lower = true; s.k0 = lo; s.k1 = mid;
-    const int nS = emit(s, small, {gT}, cS);
-    // U = T * X11 -> W1[2,1]
-    const int cU = new_counter();
+    const std::vector<Tile> st = tiles_of(s, small);
+    RowGates srow(hi);
+    for (int i = mid; i < hi; ++i) srow[i] = DagGate{new_counter(), count_row(st, i)};
+    const DagGate sall{new_counter(), (int)st.size()};
+    for (const Tile& tl : st) {
+      const DagTask tk = make(s, tl, &cu);
+      push(tk, {trow[tl.bi], trow[tl.bj]}, srow[tl.bi].cnt, sall.cnt, cu);
+    }
+    // ---- U = T * X11 -> W1[2,1]
     Op u{};
     u.flags = DAGF_ABUF | DAGF_BBUF | DAGF_BKM;  // A = W2 (T), B = W2 (X11, contraction along rows), C = W1
     u.r0 = mid; u.r1 = hi; u.c0 = lo; u.c1 = mid; u.k0 = lo; u.k1 = mid; u.klim = 2; u.tri_b = true;
-    const int nU = emit(u, small, {gT}, cU);
-    const DagGate right = rec(mid, hi, DagGate{cS, nS});
-    // X21 = -X22 * U -> W2[2,1]
-    const int cX = new_counter();
+    const std::vector<Tile> ut = tiles_of(u, small);
+    const DagGate uall{new_counter(), (int)ut.size()};
+    for (const Tile& tl : ut) {
+      const DagTask tk = make(u, tl, &cu);
+      push(tk, {trow[tl.bi]}, uall.cnt, -1, cu);
+    }
+    // ---- right subtree, gated row by row by this node's SYRK (coarse mode: by all of it)
+    RowGates rgate(hi);
+    for (int i = mid; i < hi; ++i) rgate[i] = fine_ ? srow[i] : sall;
+    const Sub right = rec(mid, hi, &rgate);
+    // ---- X21 = -X22 * U -> W2[2,1]
     Op x{};
     x.flags = DAGF_ABUF | DAGF_BKM | DAGF_CBUF | DAGF_NEG;  // A = W2 (X22), B = W1 (U, contraction along rows), C = W2
     x.r0 = mid; x.r1 = hi; x.c0 = lo; x.c1 = mid; x.k0 = mid; x.k1 = hi; x.klim = 3; x.tri_a = true;
-    const int nX = emit(x, small, {right, DagGate{cU, nU}}, cX);
-    return DagGate{cX, nX};
+    const std::vector<Tile> xt = tiles_of(x, small);
+    RowGates xrow(hi);
+    for (int i = mid; i < hi; ++i) xrow[i] = DagGate{new_counter(), count_row(xt, i)};
+    const DagGate xall{new_counter(), (int)xt.size()};
+    for (const Tile& tl : xt) {
+      const DagTask tk = make(x, tl, &cu);
+      push(tk, {fine_ ? right.rowfin[tl.bi - mid] : right.all, uall, sall}, xrow[tl.bi].cnt, xall.cnt, cu);
+    }
+    out.rowfin.resize(hi - lo);
+    for (int j = lo; j < mid; ++j) out.rowfin[j - lo] = left.rowfin[j - lo];
+    for (int j = mid; j < hi; ++j) out.rowfin[j - lo] = xrow[j];
+    out.all = xall;
+    return out;
+  }
+
+  // Reorder the queue: simulate a list schedule with nwg_ workers, priority = longest remaining path.
+  void order() {
+    const int nt = (int)plan_.tasks.size(), nc = (int)plan_.totals.size();
+    std::vector<std::vector<int>> waiters(nc);
+    for (int i = 0; i < nt; ++i)
+      for (int w = 0; w < plan_.tasks[i].nwait; ++w) waiters[plan_.tasks[i].wcnt[w]].push_back(i);
+    // bottom levels: the emission order is topological, so one reverse sweep does it
+    std::vector<double> bl(nt, 0.0), blc(nc, 0.0);
+    for (int i = nt - 1; i >= 0; --i) {
+      const DagTask& t = plan_.tasks[i];
+      double tail = 0;
+      for (int q = 0; q < DAG_MAXSIG; ++q)
+        if (t.sig[q] != DAG_NOSIG) tail = std::max(tail, blc[t.sig[q]]);
+      bl[i] = t.cost * 0.1 + tail;
+      for (int w = 0; w < t.nwait; ++w) blc[t.wcnt[w]] = std::max(blc[t.wcnt[w]], bl[i]);
+    }
+    plan_.crit_us = *std::max_element(bl.begin(), bl.end());
+    if (getenv("HBEGP_DAG_DUMP")) {  // the critical path, task by task (diagnostics)
+      int cur = (int)(std::max_element(bl.begin(), bl.end()) - bl.begin());
+      double acc_leaf = 0, acc_small = 0, acc_big = 0;
+      for (;;) {
+        const DagTask& t = plan_.tasks[cur];
+        fprintf(stderr, "crit: kind=%d row=%d col=%d depth=%d cost=%.1f remaining=%.1f flags=%x\n", t.kind, t.row0, t.col0, t.kend - t.kbeg,
+                t.cost * 0.1, bl[cur], t.flags);
+        (t.kind == DAG_LEAF ? acc_leaf : (t.kind == DAG_GEMM_64x64 ? acc_small : acc_big)) += t.cost * 0.1;
+        int nxt = -1;
+        for (int q = 0; q < DAG_MAXSIG; ++q)
+          if (t.sig[q] != DAG_NOSIG)
+            for (int wtr : waiters[t.sig[q]])
+              if (nxt < 0 || bl[wtr] > bl[nxt]) nxt = wtr;
+        if (nxt < 0) break;
+        cur = nxt;
+      }
+      fprintf(stderr, "crit totals: leaf %.0f us, 64x64 tiles %.0f us, 128x64 tiles %.0f us\n", acc_leaf, acc_small, acc_big);
+    }
+    std::vector<int> count(nc, 0), missing(nt, 0);
+    typedef std::pair<double, int> Pri;  // (bottom level, -index): highest first, earlier emission breaks ties
+    std::priority_queue<Pri> ready;
+    for (int i = 0; i < nt; ++i) {
+      missing[i] = plan_.tasks[i].nwait;
+      if (missing[i] == 0) ready.push({bl[i], -i});
+    }
+    typedef std::pair<double, int> Ev;  // (finish time, task)
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> running;
+    std::vector<DagTask> out;
+    out.reserve(nt);
+    int idle = nwg_;
+    double now = 0;
+    while ((int)out.size() < nt) {
+      while (idle > 0 && !ready.empty()) {
+        const int i = -ready.top().second;
+        ready.pop();
+        out.push_back(plan_.tasks[i]);
+        running.push({now + plan_.tasks[i].cost * 0.1, i});
+        --idle;
+      }
+      if (running.empty()) break;  // cannot happen for a sound graph
+      const Ev e = running.top();
+      running.pop();
+      now = e.first;
+      ++idle;
+      const DagTask& t = plan_.tasks[e.second];
+      for (int q = 0; q < DAG_MAXSIG; ++q) {
+        if (t.sig[q] == DAG_NOSIG) continue;
+        const int c = t.sig[q];
+        if (++count[c] == plan_.totals[c])
+          for (int wtr : waiters[c])
+            if (--missing[wtr] == 0) ready.push({bl[wtr], -wtr});
+      }
+    }
+    while (!running.empty()) { now = running.top().first; running.pop(); }
+    if ((int)out.size() == nt) {
+      plan_.tasks.swap(out);
+      plan_.sim_us = now;
+    }
   }
 };
 
@@ -204,9 +364,11 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
   cells[1].resize((size_t)nt64 * nt64);
   std::vector<std::vector<uint64_t>> known(nt);
   auto hb = [&](int a, int b) -> bool {  // task a happened before task b starts
-    const int c = plan.tasks[a].sig;
-    if (c == DAG_NOSIG) return false;
-    return ((known[b][c / 64] >> (c % 64)) & 1u) != 0;
+    for (int q = 0; q < DAG_MAXSIG; ++q) {
+      const int c = plan.tasks[a].sig[q];
+      if (c != DAG_NOSIG && ((known[b][c / 64] >> (c % 64)) & 1u) != 0) return true;
+    }
+    return false;
   };
   for (int i = 0; i < nt; ++i) {
     const DagTask& t = plan.tasks[i];
@@ -270,8 +432,9 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
       if (a.write) { cell.writer = i; cell.readers.clear(); }
       else if (cell.readers.empty() || cell.readers.back() != i) cell.readers.push_back(i);
     }
-    if (t.sig != DAG_NOSIG) {
-      const int c = t.sig;
+    for (int sq = 0; sq < DAG_MAXSIG; ++sq) {
+      if (t.sig[sq] == DAG_NOSIG) continue;
+      const int c = t.sig[sq];
       if (c >= nc) return "bump of an unknown counter";
       count[c]++;
       for (int q = 0; q < words; ++q) counter_known[(size_t)c * words + q] |= cur[q];

@@ -81,16 +81,20 @@ enum : uint16_t {
   DAGF_ACC = 64,   // beta = 1
 };
 constexpr int DAG_MAXWAIT = 4;
+constexpr int DAG_MAXSIG = 2;
 constexpr uint16_t DAG_NOSIG = 0xffff;
 struct DagTask {
   uint16_t kind, flags;
   int32_t row0, col0;  // origin of the output tile (elements); leaf: row0 = index of the 128-block
   int32_t kbeg, kend;  // contraction range (elements, whole stages)
-  uint16_t nwait, sig;
-  uint16_t wcnt[DAG_MAXWAIT];
-  int32_t wval[DAG_MAXWAIT];
+  uint16_t nwait;
+  uint16_t sig[DAG_MAXSIG];    // counters bumped once the task's results are visible (DAG_NOSIG: unused)
+  uint16_t wcnt[DAG_MAXWAIT];  // counters waited for ...
+  uint16_t wval[DAG_MAXWAIT];  // ... to reach these values (always the counter's full count)
+  uint16_t cost;               // host-side estimate (tenths of a microsecond) used to order the queue
+  uint16_t pad_[2];
 };
-static_assert(sizeof(DagTask) == 48, "DagTask layout");
+static_assert(sizeof(DagTask) == 48, "DagTask layout");  // dag_kernel decodes it dword by dword: keep the field order
 constexpr int DAG_CTRL_WORDS = 4;     // ctrl[0] queue head, [1] first task that gave up waiting (+1), [2..3] spare; counters follow
 constexpr int DAG_INFO_TIMEOUT = -2;  // written to EvalOut::info when a wait exceeded its bound (a bug, never a data property)
 struct DagLaunch {
@@ -102,6 +106,7 @@ struct DagLaunch {
   int ld;
   void* ldiag;
   int* info;
+  unsigned long long* trace;  // optional (diagnostics): per task [pulled, inputs ready, computed, published] on the 100 MHz clock, then the CU id
 };
 template <typename T>
 void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);

@@ -292,6 +292,7 @@ struct Slot {
   double *part_t = nullptr, *part_g = nullptr;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
+  unsigned long long* dag_trace = nullptr;  // HBEGP_DAG_TRACE: per-task time stamps of the last evaluation
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
   EvalOut* hOut = nullptr;   // pinned
@@ -326,6 +327,7 @@ struct Problem : ProblemBase {
   bool dag_ = false;
   std::vector<DagTask*> dag_tasks;          // per device
   int dag_ntasks = 0, dag_nwg = 0;
+  std::vector<DagTask> dag_host_tasks;      // kept for the trace dump
   size_t dag_ctrl_bytes = 0;
   double dag_gflop = 0;
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
@@ -390,31 +392,51 @@ struct Problem : ProblemBase {
     }
     // Task queue of the factorisation.  The workgroups of one launch hold a CU each while they wait for the diagonal
     // blocks, so a problem whose slots run concurrently shares the CUs between its slots.
-    const int dag_env = env_int("HBEGP_DAG", 1);  // read per problem: the parity tests flip it inside one process
-    dag_ = dag_env != 0 && !adhoc_ && np / NB >= 2;
+    // Default: on for problems whose slots run concurrently (a fit: the optimiser runs share the chip, and a resident
+    // task-queue kernel keeps its CUs while another run's tile GEMMs fill the rest: measured 1.30 -> 1.56 fit+predict/s
+    // on config M); a single evaluation stream is a few per cent faster as a chain of launches (2.89 vs 3.04 ms).
+    // HBEGP_DAG=0/1 forces it (read per problem: the parity tests flip it inside one process).
+    const int dag_env = env_int("HBEGP_DAG", -1);
+    dag_ = (dag_env < 0 ? n_slots >= 2 : dag_env != 0) && !adhoc_ && np / NB >= 2;
     if (dag_) {
-      DagBuilder builder(is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 2));
+      int cus = 256;
+      {
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, c->devs[0]));
+        cus = std::max(1, prop.multiProcessorCount);
+      }
+      const int forced = env_int("HBEGP_DAG_WG", 0);
+      dag_nwg = forced > 0 ? forced : std::max(1, cus / std::max(1, n_slots));
+      DagBuilder builder(is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
+                         env_int("HBEGP_DAG_FINE", 1) != 0);
       DagPlan plan = builder.build(0, np / NB);
-      if (env_int("HBEGP_DAG_VALIDATE", 0)) {
+      if (plan.tasks.empty()) dag_ = false;  // too many counters for 16-bit ids (n > 32k): launch-per-product path
+      if (dag_ && env_int("HBEGP_DAG_VALIDATE", 0)) {
         const std::string why = dag_plan_validate(plan, np / NB);
         if (!why.empty()) throw std::runtime_error("task queue of the factorisation is unsound: " + why);
       }
-      dag_ntasks = (int)plan.tasks.size();
-      dag_gflop = plan.gflop;
-      dag_ctrl_bytes = (sizeof(int) * (DAG_CTRL_WORDS + plan.totals.size()) + 15) / 16 * 16;
-      dag_tasks.assign(c->devs.size(), nullptr);
-      for (size_t di = 0; di < c->devs.size(); ++di) {
-        HIPCHECK(hipSetDevice(c->devs[di]));
-        hipDeviceProp_t prop;
-        HIPCHECK(hipGetDeviceProperties(&prop, c->devs[di]));
-        const int forced = env_int("HBEGP_DAG_WG", 0);
-        dag_nwg = forced > 0 ? forced : std::max(1, prop.multiProcessorCount / std::max(1, n_slots));
+      if (dag_ && env_int("HBEGP_DAG_VERBOSE", 0))
+        fprintf(stderr, "dag plan: %zu tasks, %zu counters, %d workgroups, critical path %.0f us, simulated %.0f us, %.2f GFLOP\n",
+                plan.tasks.size(), plan.totals.size(), dag_nwg, plan.crit_us, plan.sim_us, plan.gflop);
+      if (dag_) {
+        dag_ntasks = (int)plan.tasks.size();
         dag_nwg = std::min(dag_nwg, dag_ntasks);
-        HIPCHECK(hipMalloc(&dag_tasks[di], sizeof(DagTask) * plan.tasks.size()));
-        HIPCHECK(hipMemcpy(dag_tasks[di], plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
-        for (auto& s : slots[di]) {
-          HIPCHECK(hipMalloc(&s.dag_ctrl, dag_ctrl_bytes));
-          HIPCHECK(hipMemset(s.dag_ctrl, 0, dag_ctrl_bytes));
+        dag_gflop = plan.gflop;
+        dag_ctrl_bytes = (sizeof(int) * (DAG_CTRL_WORDS + plan.totals.size()) + 15) / 16 * 16;
+        dag_tasks.assign(c->devs.size(), nullptr);
+        for (size_t di = 0; di < c->devs.size(); ++di) {
+          HIPCHECK(hipSetDevice(c->devs[di]));
+          HIPCHECK(hipMalloc(&dag_tasks[di], sizeof(DagTask) * plan.tasks.size()));
+          HIPCHECK(hipMemcpy(dag_tasks[di], plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
+          for (auto& s : slots[di]) {
+            HIPCHECK(hipMalloc(&s.dag_ctrl, dag_ctrl_bytes));
+            HIPCHECK(hipMemset(s.dag_ctrl, 0, dag_ctrl_bytes));
+            if (getenv("HBEGP_DAG_TRACE")) {
+              HIPCHECK(hipMalloc(&s.dag_trace, sizeof(unsigned long long) * 5 * plan.tasks.size()));
+              HIPCHECK(hipMemset(s.dag_trace, 0, sizeof(unsigned long long) * 5 * plan.tasks.size()));
+            }
+          }
+          dag_host_tasks = plan.tasks;
         }
       }
     }
@@ -442,7 +464,7 @@ struct Problem : ProblemBase {
         g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb);
         for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
         (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
-        (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl);
+        (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace);
         (void)hipHostFree(s.hP); (void)hipHostFree(s.hOut);
         if (s.stream) (void)hipStreamDestroy(s.stream);
       }
@@ -580,6 +602,7 @@ struct Problem : ProblemBase {
       DagLaunch g{};
       g.tasks = dag_tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
       g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
+      g.trace = s.dag_trace;
       if (tm) tm->begin(PhaseTimer::DAG, 0, dag_gflop);
       launch_dag<T>(g, dag_nwg, s.stream);
       if (tm) tm->end();
@@ -898,6 +921,21 @@ struct Problem : ProblemBase {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (s.dag_trace && getenv("HBEGP_DAG_TRACE")) {
+      // one more graph replay on a quiet device, then dump: idx kind row col depth nwait | pulled ready computed published (ticks of 10 ns) | xcc hwid
+      if (s.graph[0][1]) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
+      HIPCHECK(hipStreamSynchronize(s.stream));
+      std::vector<unsigned long long> tr((size_t)5 * dag_ntasks);
+      HIPCHECK(hipMemcpy(tr.data(), s.dag_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(getenv("HBEGP_DAG_TRACE"), "w")) {
+        for (int i = 0; i < dag_ntasks; ++i) {
+          const DagTask& t = dag_host_tasks[i];
+          fprintf(f, "%d %d %d %d %d %d %llu %llu %llu %llu %llu %llu\n", i, t.kind, t.row0, t.col0, t.kend - t.kbeg, t.nwait, tr[5 * i], tr[5 * i + 1],
+                  tr[5 * i + 2], tr[5 * i + 3], tr[5 * i + 4] >> 32, tr[5 * i + 4] & 0xffffffffull);
+        }
+        fclose(f);
+      }
+    }
     return HBEGP_OK;
   }
 };
@@ -1514,17 +1552,19 @@ void hbegp_model_release(hbegp_model* model) {
   if (model && model->refs.fetch_sub(1) == 1) delete model;
 }
 
-int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int* ntasks, int* ncounters, int* nleaf, double* gflop, char* err,
-                         int errlen) {
-  if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0) return fail(HBEGP_EINVAL, "bad argument");
+int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, int* ntasks, int* ncounters, int* nleaf,
+                         double* gflop, double* crit_us, double* sim_us, char* err, int errlen) {
+  if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0 || nwg < 0) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
-  DagBuilder builder(bk, small_h);
+  DagBuilder builder(bk, small_h, nwg, fine != 0);
   const DagPlan plan = builder.build(0, nblocks);
-  const std::string why = dag_plan_validate(plan, nblocks);
+  const std::string why = plan.tasks.empty() ? std::string("too many counters") : dag_plan_validate(plan, nblocks);
   if (ntasks) *ntasks = (int)plan.tasks.size();
   if (ncounters) *ncounters = (int)plan.totals.size();
   if (nleaf) *nleaf = plan.n_leaf;
   if (gflop) *gflop = plan.gflop;
+  if (crit_us) *crit_us = plan.crit_us;
+  if (sim_us) *sim_us = plan.sim_us;
   if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", why.c_str());
   return why.empty() ? HBEGP_OK : fail(HBEGP_EINVAL, "%s", why.c_str());
   GUARD_END

@@ -163,10 +163,12 @@ double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, c
 
 /* ---- test hook (host only, no GPU): build the task queue of the device-scheduled factorisation for `nblocks`
  * 128-blocks (bk = contraction elements per stage: 16 for f64, 32 for f32; nodes up to small_h blocks wide use 64x64
- * tiles) and check it: queue order topological (=> deadlock-free for any number of resident workgroups), every wait
- * for a full count, no unordered access to a tile.  Returns HBEGP_OK or HBEGP_EINVAL with the reason in err. */
-int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int* ntasks, int* ncounters, int* nleaf, double* gflop,
-                         char* err, int errlen);
+ * tiles; nwg > 0: order the queue by a list schedule simulated for nwg workgroups; fine: per-row-block dependencies) and
+ * check it: queue order topological (=> deadlock-free for any number of resident workgroups), every wait for a full
+ * count, no unordered access to a tile.  crit_us / sim_us: critical path and simulated makespan under the host's task
+ * time estimates.  Returns HBEGP_OK or HBEGP_EINVAL with the reason in err. */
+int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, int* ntasks, int* ncounters, int* nleaf,
+                         double* gflop, double* crit_us, double* sim_us, char* err, int errlen);
 
 #ifdef __cplusplus
 }

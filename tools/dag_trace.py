@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Analyse a task trace of the device-scheduled factorisation (HBEGP_DAG_TRACE=<file>, written by hbegp_problem_time_eval).
+Columns: idx kind row col depth nwait pulled ready computed published xcc hwid   (times in ticks of 10 ns).
+Prints per task class: count, compute time (ready -> computed), publish time (computed -> published), wait (pulled -> ready)."""
+import sys
+import numpy as np
+
+a = np.loadtxt(sys.argv[1], dtype=np.int64)
+t0 = a[:, 6].min()
+pulled, ready, comp, pub = [(a[:, c] - t0) * 0.01 for c in (6, 7, 8, 9)]  # microseconds
+kind, depth, nwait = a[:, 1], a[:, 4], a[:, 5]
+print(f"tasks {len(a)}  makespan {pub.max():.1f} us  CUs used {len(set(zip(a[:,10], a[:,11] & 0xffffff00)))}")
+names = {0: "gemm128x64", 1: "gemm64x64", 2: "leaf"}
+print(f"{'class':24s} {'n':>5s} {'compute':>9s} {'publish':>9s} {'wait':>9s} {'total busy us':>14s}")
+for k in (2, 1, 0):
+    for d in sorted(set(depth[kind == k])):
+        m = (kind == k) & (depth == d)
+        c, p, w = comp[m] - ready[m], pub[m] - comp[m], ready[m] - pulled[m]
+        print(f"{names[k] + ' k=' + str(d):24s} {m.sum():5d} {np.median(c):9.2f} {np.median(p):9.2f} {np.median(w):9.2f} {(pub[m] - ready[m]).sum():14.0f}")
+busy = (pub - ready).sum()
+held = (pub - pulled).sum()
+print(f"sum busy {busy:.0f} us, sum held (incl. waiting) {held:.0f} us, makespan x CUs = {pub.max() * len(set(zip(a[:,10], a[:,11] & 0xffffff00))):.0f}")
+# leaf chain: time between consecutive leaves becoming ready
+lm = kind == 2
+order = np.argsort(ready[lm])
+lr, lp = ready[lm][order], pub[lm][order]
+gaps = lr[1:] - lp[:-1]
+print("leaf chain: leaf busy median %.1f us; gap leaf(k) published -> leaf(k+1) ready: median %.1f max %.1f sum %.0f us" % (np.median(lp - lr), np.median(gaps), gaps.max(), gaps.sum()))
+print("gaps:", " ".join(f"{g:.0f}" for g in gaps))
