@@ -313,6 +313,7 @@ struct ProblemBase {
   virtual ~ProblemBase() {}
   virtual int eval(int dev, int slot, const double* theta, const double* lo, const double* hi, double* lml, double* grad) = 0;
   virtual int time_eval(int dev, int slot, const double* theta, int reps, double* phase_ms) = 0;
+  virtual int time_concurrent(int dev, const double* theta, int reps, double* out) = 0;
 };
 struct hbegp_problem {
   std::unique_ptr<ProblemBase> impl;
@@ -938,6 +939,88 @@ struct Problem : ProblemBase {
     }
     return HBEGP_OK;
   }
+
+  int time_concurrent(int dev, const double* theta, int reps, double* out) override {
+    if (dev < 0 || dev >= (int)slots.size()) return fail(HBEGP_EINVAL, "bad device index");
+    const size_t di = (size_t)dev;
+    const int ns = n_slots;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    out[1] = ns;
+    out[10] = dag_ ? dag_nwg : 0;
+    std::string err;
+    std::mutex err_mu;
+    // pass 0: warm-up (graph instantiation), pass 1: graph replay, pass 2: eager with events
+    std::vector<double> acc(12, 0.0);
+    std::mutex acc_mu;
+    for (int pass = 0; pass < 3; ++pass) {
+      std::atomic<int> arrived{0};
+      std::vector<double> wall(ns, 0.0);
+      auto worker = [&](int si) {
+        try {
+          Slot<T>& s = slots[di][si];
+          HIPCHECK(hipSetDevice(s.dev));
+          theta_to_params(theta, nullptr, nullptr, d, s.hP);
+          std::vector<double> grad(d + 2);
+          double lml;
+          arrived.fetch_add(1);
+          while (arrived.load() < ns) std::this_thread::yield();  // start together
+          const auto t0 = std::chrono::steady_clock::now();
+          const int nrep = pass == 0 ? 1 : reps;
+          for (int r = 0; r < nrep; ++r) {
+            if (pass < 2) {
+              const int st = run_eval(di, si, 0, true, true, &lml, grad.data());
+              if (st != HBEGP_OK) throw std::runtime_error("evaluation failed (not positive definite) at the timing theta");
+            } else {
+              PhaseTimer tm;
+              tm.s = s.stream;
+              enqueue_eval(s, di, 0, true, &tm);
+              HIPCHECK(hipStreamSynchronize(s.stream));
+              std::vector<double> loc(12, 0.0);
+              for (auto& rec : tm.recs) {
+                float dt = 0;
+                HIPCHECK(hipEventElapsedTime(&dt, rec.a, rec.b));
+                if (rec.kind == PhaseTimer::KMAT) loc[3] += dt;
+                if (rec.kind == PhaseTimer::DAG || rec.kind == PhaseTimer::GEMM || rec.kind == PhaseTimer::LEAF) { loc[4] += dt; loc[5] += rec.gflop; loc[11] += 1; }
+                if (rec.kind == PhaseTimer::LAUUM) { loc[6] += dt; loc[7] += rec.gflop; }
+                if (rec.kind == PhaseTimer::ALPHA) loc[8] += dt;
+                if (rec.kind == PhaseTimer::GRAD) loc[9] += dt;
+                (void)hipEventDestroy(rec.a);
+                (void)hipEventDestroy(rec.b);
+              }
+              std::lock_guard<std::mutex> lk(acc_mu);
+              for (int i = 0; i < 12; ++i) acc[i] += loc[i] / ((double)nrep * ns);
+            }
+          }
+          wall[si] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nrep;
+        } catch (const HipError& he) {
+          hip_fail(he);
+          std::lock_guard<std::mutex> lk(err_mu);
+          err = g_last_error;
+          arrived.fetch_add(ns);  // never leave the others spinning at the start line
+        } catch (const std::exception& e) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          err = e.what();
+          arrived.fetch_add(ns);
+        }
+      };
+      std::vector<std::thread> threads;
+      try {
+        for (int si = 0; si < ns; ++si) threads.emplace_back(worker, si);
+      } catch (...) {
+        arrived.fetch_add(ns);
+        for (auto& t : threads) t.join();
+        throw;
+      }
+      for (auto& t : threads) t.join();
+      if (!err.empty()) return fail(HBEGP_EHIP, "%s", err.c_str());
+      const double wmax = *std::max_element(wall.begin(), wall.end());
+      if (pass == 1) out[0] = wmax;
+      if (pass == 2) out[2] = wmax;
+    }
+    for (int i = 3; i < 12; ++i)
+      if (i != 10) out[i] = acc[i];
+    return HBEGP_OK;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1089,6 +1172,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   }
   std::mutex trace_mu;
   int trace_n = 0;
+  std::atomic<int> n_evals{0}, n_not_pd{0};
   std::string err;
   std::mutex err_mu;
 
@@ -1111,6 +1195,8 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
           double lml;
           const int st = prob.run_eval((size_t)di, si, target, true, true, &lml, grad);
           const int my_eval = eval_idx++;
+          n_evals.fetch_add(1);
+          if (st != HBEGP_OK) n_not_pd.fetch_add(1);
           if (opt.trace_cap > 0) {
             std::lock_guard<std::mutex> lk(trace_mu);
             if (trace_n < opt.trace_cap) {
@@ -1177,6 +1263,8 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
     permute(opt.trace_run, 1);
   }
   if (opt.trace_count) *opt.trace_count = trace_n;
+  if (opt.n_evals) *opt.n_evals = n_evals.load();
+  if (opt.n_not_pd) *opt.n_not_pd = n_not_pd.load();
   if (!err.empty()) return fail(HBEGP_EHIP, "%s", err.c_str());
 
   // global arg-max over the per-slot captures, ties -> lowest (run, eval)
@@ -1371,6 +1459,13 @@ int hbegp_problem_eval(hbegp_problem* prob, int dev, int slot, const double* the
   GUARD_END
 }
 
+int hbegp_problem_time_concurrent(hbegp_problem* prob, int dev, const double* theta, int reps, double* out) {
+  if (!prob || !theta || !out || reps < 1) return fail(HBEGP_EINVAL, "bad argument");
+  GUARD_BEGIN
+  return prob->impl->time_concurrent(dev, theta, reps, out);
+  GUARD_END
+}
+
 int hbegp_problem_time_eval(hbegp_problem* prob, int dev, int slot, const double* theta, int reps, double* phase_ms) {
   if (!prob || !theta || reps < 1) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
@@ -1557,7 +1652,21 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0 || nwg < 0) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
   DagBuilder builder(bk, small_h, nwg, fine != 0);
-  const DagPlan plan = builder.build(0, nblocks);
+  DagPlan plan = builder.build(0, nblocks);
+  // fault injection for the validator's own test: HBEGP_DAG_TEST_FAULT = "drop:<i>" (task i loses its first wait) or
+  // "move:<i>:<j>" (task i is moved to queue position j)
+  if (const char* fault = getenv("HBEGP_DAG_TEST_FAULT")) {
+    int a = 0, b = 0;
+    if (sscanf(fault, "drop:%d", &a) == 1 && a >= 0 && a < (int)plan.tasks.size() && plan.tasks[a].nwait > 0) {
+      DagTask& t = plan.tasks[a];
+      for (int w = 1; w < t.nwait; ++w) { t.wcnt[w - 1] = t.wcnt[w]; t.wval[w - 1] = t.wval[w]; }
+      t.nwait--;
+    } else if (sscanf(fault, "move:%d:%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < (int)plan.tasks.size() && b < (int)plan.tasks.size()) {
+      const DagTask t = plan.tasks[a];
+      plan.tasks.erase(plan.tasks.begin() + a);
+      plan.tasks.insert(plan.tasks.begin() + b, t);
+    }
+  }
   const std::string why = plan.tasks.empty() ? std::string("too many counters") : dag_plan_validate(plan, nblocks);
   if (ntasks) *ntasks = (int)plan.tasks.size();
   if (ncounters) *ncounters = (int)plan.totals.size();

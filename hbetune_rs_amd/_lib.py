@@ -32,6 +32,8 @@ class FitOptions(C.Structure):
         ("trace_grad", C.POINTER(C.c_double)),
         ("trace_run", C.POINTER(C.c_int)),
         ("trace_count", C.POINTER(C.c_int)),
+        ("n_evals", C.POINTER(C.c_int)),
+        ("n_not_pd", C.POINTER(C.c_int)),
     ]
 
 
@@ -58,6 +60,7 @@ SIGNATURES = {
     "hbegp_problem_kmat_f64": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "hbegp_problem_kmat_f32": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _fp]),
     "hbegp_problem_time_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp]),
+    "hbegp_problem_time_concurrent": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp]),
     "hbegp_fit_f64": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, C.c_int,
                                 C.POINTER(FitOptions), _dp, _dp, C.POINTER(_vp)]),
     "hbegp_fit_f32": (C.c_int, [_vp, _fp, _fp, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, C.c_int,

@@ -134,6 +134,17 @@ class Problem:
                 "n_gemm128", "n_gemm64", "n_gemm32", "dag_ms", "dag_gflop", "r1", "r2", "r3"]
         return dict(zip(keys, phases.tolist()))
 
+    def time_concurrent(self, theta, reps=5, dev=0):
+        """Every slot evaluating at once (the configuration a fit runs in): wall time per round and per-kernel-class times
+        from hipEvents on each slot's stream."""
+        lib = _lib.load()
+        theta = _lib.as_c(theta, np.float64)
+        out = np.zeros(16)
+        _lib.check(lib.hbegp_problem_time_concurrent(self._h, dev, _lib.dptr(theta), reps, _lib.dptr(out)))
+        keys = ["round_ms", "n_slots", "round_eager_ms", "kmat_ms", "factor_ms", "factor_gflop", "lauum_ms", "lauum_gflop", "alpha_ms",
+                "gradtrace_ms", "task_queue_workgroups", "factor_launches"]
+        return dict(zip(keys, out.tolist()))
+
 
 class FittedKernel:
     """Mirror of `FittedKernel<K, A>` (fit.rs:6-12): kernel parameters, noise, alpha, k_inv, lml + the model handle."""
@@ -191,6 +202,9 @@ class FittedKernel:
         opt = _lib.FitOptions()
         opt.maxeval = maxeval
         opt.fixed_work = 1 if fixed_work else 0
+        n_evals, n_not_pd = C.c_int(0), C.c_int(0)
+        opt.n_evals = C.pointer(n_evals)
+        opt.n_not_pd = C.pointer(n_not_pd)
         tr = None
         if trace:
             cap = (1 + n_restarts) * maxeval
@@ -209,6 +223,7 @@ class FittedKernel:
         _lib.check(fit(ctx._h, _lib.aptr(x), _lib.aptr(y), n, d, float(nu), _lib.dptr(theta0), _lib.dptr(lo), _lib.dptr(hi),
                        _lib.dptr(starts_c), n_restarts, C.byref(opt), _lib.dptr(theta_best), C.byref(lml_best), C.byref(handle)))
         fk = FittedKernel(handle, dtype, n, d, nu)
+        fk.n_evals, fk.n_not_pd = n_evals.value, n_not_pd.value
         if trace:
             k = tr["count"].value
             fk.trace = dict(theta=tr["theta"][:k], lml=tr["lml"][:k], grad=tr["grad"][:k], run=tr["run"][:k])

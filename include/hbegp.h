@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HBEGP_VERSION 101 /* 0.1.1: + hbegp_extend_from_* */
+#define HBEGP_VERSION 102 /* 0.1.2: + hbegp_problem_time_concurrent, hbegp_fit_options.n_evals / n_not_pd, hbegp_debug_dag_plan */
 
 enum {
   HBEGP_OK = 0,
@@ -94,6 +94,15 @@ int hbegp_problem_kmat_f32(hbegp_problem* prob, int dev, int slot, const double*
 int hbegp_problem_time_eval(hbegp_problem* prob, int dev, int slot, const double* theta, int reps,
                             double* phase_ms);
 
+/* Timed evaluations in the configuration a fit runs in: `reps` evaluations at theta on EVERY slot of device index `dev` at
+ * once, one host thread per slot.  out must have room for 16 doubles:
+ * [0] wall ms per round (every slot finishes one evaluation) with graph replay, [1] number of slots,
+ * [2] the same with eager launches and one hipEvent pair per launch group, on each slot's stream; per evaluation, mean over
+ * slots and repetitions, from those events: [3] kmat ms, [4] factorisation ms (task-queue launch, or diagonal-block +
+ * tile-GEMM launches), [5] its algorithmic GFLOP, [6] lauum ms, [7] its GFLOP, [8] alpha/lml ms, [9] gradtrace ms,
+ * [10] workgroups of the task-queue launch (0: launch-per-product path), [11] launches of [4] per evaluation. */
+int hbegp_problem_time_concurrent(hbegp_problem* prob, int dev, const double* theta, int reps, double* out);
+
 /* ---- fit / extend: mirrors FittedKernel::new / ::extend (fit.rs:18-68, 71-176) --------------------- */
 typedef struct hbegp_fit_options {
   int maxeval;      /* evaluations per optimiser run; the reference uses 150 (gradmin.rs:54) */
@@ -109,6 +118,8 @@ typedef struct hbegp_fit_options {
   double* trace_grad;
   int* trace_run;
   int* trace_count; /* out: number of evaluations recorded */
+  int* n_evals;     /* out (may be NULL): evaluations run, all optimiser runs together */
+  int* n_not_pd;    /* out (may be NULL): evaluations whose kernel matrix was not positive definite (objective +inf, fit.rs:105-112) */
 } hbegp_fit_options;
 
 /* Maximise the log marginal likelihood over theta in [ln lo, ln hi] with 1 + n_restarts bounded L-BFGS runs:

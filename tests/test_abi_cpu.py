@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/hbegp.h but not exported by libhbegp.so"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.hbegp_version() == 101
+    assert lib.hbegp_version() == 102
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -1,0 +1,54 @@
+"""CPU: the task queue of the device-scheduled factorisation (csrc/dag_plan.hpp) is sound for every shape the engine
+builds -- queue order topological (so any number of resident workgroups makes progress: no deadlock by construction),
+every wait for a full count, no unordered access to a tile of W1/W2 -- and the checker itself catches broken plans."""
+import ctypes as C
+import os
+
+import pytest
+
+from hbetune_rs_amd import _lib
+
+
+def plan(nb, bk=16, small_h=8, nwg=85, fine=1):
+    lib = _lib.load()
+    nt, nc, nl = C.c_int(), C.c_int(), C.c_int()
+    gf, cr, sm = C.c_double(), C.c_double(), C.c_double()
+    err = C.create_string_buffer(400)
+    rc = lib.hbegp_debug_dag_plan(nb, bk, small_h, nwg, fine, C.byref(nt), C.byref(nc), C.byref(nl), C.byref(gf), C.byref(cr),
+                                  C.byref(sm), err, 400)
+    return rc, dict(ntasks=nt.value, ncounters=nc.value, nleaf=nl.value, gflop=gf.value, crit_us=cr.value, sim_us=sm.value,
+                    err=err.value.decode())
+
+
+@pytest.mark.parametrize("nb", list(range(1, 20)) + [24, 31, 32, 33, 48, 64])
+def test_plans_are_sound_for_every_block_count(nb):
+    ref = None
+    for bk in (16, 32):
+        for small_h, nwg, fine in [(8, 85, 1), (2, 256, 1), (0, 1, 1), (64, 7, 1), (8, 0, 1), (8, 85, 0), (2, 0, 0)]:
+            rc, info = plan(nb, bk, small_h, nwg, fine)
+            assert rc == 0, (nb, bk, small_h, nwg, fine, info["err"])
+            assert info["nleaf"] == nb
+            ref = ref or info["gflop"]
+            assert info["gflop"] == pytest.approx(ref, rel=1e-12)  # the work does not depend on tiling, order or dependencies
+            if nwg > 0 and nb > 1:
+                assert info["crit_us"] > 0 and info["sim_us"] >= info["crit_us"] - 1e-6
+
+
+def test_flops_match_potrf_plus_trtri():
+    # n = 4096: the recursion carries n^3/3 (Cholesky) + n^3/3 (inverse of the factor) minus what the half-counted
+    # triangles save; LAUUM (the last third, 22.9 GFLOP) is a separate launch.  DESIGN.md quotes 68.7 - 22.95 = 45.8.
+    rc, info = plan(32)
+    assert rc == 0 and info["gflop"] == pytest.approx(45.77, abs=0.02)
+
+
+def test_look_ahead_shortens_the_simulated_schedule():
+    _, fine = plan(32, nwg=85, fine=1)
+    _, coarse = plan(32, nwg=85, fine=0)
+    assert fine["sim_us"] < 0.85 * coarse["sim_us"]
+
+
+@pytest.mark.parametrize("fault", ["drop:40", "drop:200", "drop:900", "drop:2500", "move:3000:10", "move:500:100"])
+def test_checker_rejects_broken_plans(fault, monkeypatch):
+    monkeypatch.setenv("HBEGP_DAG_TEST_FAULT", fault)
+    rc, info = plan(32)
+    assert rc == _lib.EINVAL and info["err"], fault

@@ -1,0 +1,93 @@
+"""GPU: the device-scheduled factorisation (one persistent task-queue launch, csrc/dag_kernel.inc.hpp) against the
+launch-per-product path and the oracle.  Per output element both paths run the same sequence of MFMA accumulations, so
+lml, gradient, alpha, K^-1 and diag(L) must be bitwise equal; the oracle comparison pins both to lml.rs:29-79."""
+import math
+
+import numpy as np
+import pytest
+
+from hbetune_rs_amd import gpr, synth
+from oracle import gpr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _eval_all(X, y, theta, monkeypatch, dag, n_slots=1, reps=2, **env):
+    monkeypatch.setenv("HBEGP_DAG", dag)
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    prob = gpr.Problem(X, y, n_slots=n_slots)
+    out = []
+    for rep in range(reps):
+        r = prob.lml_with_gradient(theta + 0.02 * rep)
+        out.append((r, prob.results()))
+    prob.close()
+    return out
+
+
+@pytest.mark.parametrize("n,cfg,dtype", [(200, "C2", np.float64), (256, "C1", np.float64), (300, "M", np.float64), (1100, "C3", np.float64),
+                                          (2048, "M", np.float64), (600, "C5", np.float32), (1536, "C5", np.float32)])
+def test_task_queue_is_bitwise_equal_to_launch_path(n, cfg, dtype, monkeypatch):
+    w = synth.make_workload(cfg, n=n)
+    X, y, theta = w["X"].astype(dtype), w["y"].astype(dtype), w["theta"].copy()
+    if dtype == np.float32:
+        theta[0] = theta[1] + math.log(0.5)
+    ref = _eval_all(X, y, theta, monkeypatch, "0")
+    for wg, small_h in [(0, 8), (3, 2), (40, 0)]:  # any number of workgroups must give the same bits (and terminate)
+        got = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_WG=wg, HBEGP_DAG_SMALLH=small_h, HBEGP_DAG_VALIDATE=1)
+        for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(ref, got):
+            assert r0 is not None and r1 is not None
+            assert r0[0] == r1[0] and np.array_equal(r0[1], r1[1])
+            assert np.array_equal(a0, a1) and np.array_equal(k0, k1) and np.array_equal(l0, l1)
+
+
+def test_task_queue_matches_oracle(monkeypatch):
+    w = synth.make_workload("C2", n=700)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    (r, (alpha, kinv, ldiag)), = _eval_all(X, y, theta, monkeypatch, "1", reps=1)
+    s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+    ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+    assert abs(r[0] - ref["lml"]) <= 1e-8 * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(r[1], ref["grad"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["grad"]).max()))
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["alpha"]).max()))
+    np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["k_inv"]).max()))
+
+
+def test_task_queue_drains_when_not_positive_definite(monkeypatch):
+    # lml.rs:47-50: the failing diagonal block flags the evaluation; every later task skips its work but still bumps its
+    # counters, so the queue drains at once and the slot is usable again
+    monkeypatch.setenv("HBEGP_DAG", "1")
+    rng = np.random.default_rng(5)
+    X = rng.random((400, 3))
+    X[300] = X[10]  # duplicate rows + vanishing noise: block 2 fails, blocks 0-1 succeed
+    y = rng.random(400)
+    prob = gpr.Problem(X, y)
+    assert prob.lml_with_gradient(np.array([math.log(1e-300), 0.0, 0.0, 0.0, 0.0])) is None
+    ok = prob.lml_with_gradient(np.array([math.log(1e-2), 0.0, 0.0, 0.0, 0.0]))
+    assert ok is not None and np.isfinite(ok[0]) and np.all(np.isfinite(ok[1]))
+
+
+def test_concurrent_slots_share_the_chip_and_agree(monkeypatch):
+    # three slots evaluated from three host threads (what a fit does): each slot's launch holds a third of the CUs
+    import threading
+
+    monkeypatch.delenv("HBEGP_DAG", raising=False)  # default: task queue on for problems with concurrent slots
+    w = synth.make_workload("M", n=1500)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    prob = gpr.Problem(X, y, n_slots=3)
+    res = [None] * 3
+
+    def work(slot):
+        vals = []
+        for rep in range(6):
+            vals.append(prob.lml_with_gradient(theta + 0.01 * ((rep + slot) % 3), slot=slot))
+        res[slot] = vals
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    single = {k: gpr.Problem(X, y).lml_with_gradient(theta + 0.01 * k) for k in range(3)}
+    for slot in range(3):
+        for rep in range(6):
+            k = (rep + slot) % 3
+            assert res[slot][rep][0] == single[k][0] and np.array_equal(res[slot][rep][1], single[k][1])
