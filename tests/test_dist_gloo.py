@@ -60,3 +60,29 @@ def test_shard_units_partition():
     for world in (1, 2, 3, 4, 8):
         seen = sorted(u for r in range(world) for u in D.shard_units(8, world, r))
         assert seen == list(range(8))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a torchrun environment must start two ranks itself and report n_gpus = 2
+    (rehearsed on CPU with --dry: gloo, no GPU work; the barrier / max-over-ranks / rank-0 print are the real ones)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--dry"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["ms_per_step"] >= 19.0  # rank 1 takes 20 ms per step: MAX over ranks, not rank 0's 10 ms
+
+
+def test_bench_refuses_a_mismatched_world(tmp_path):
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=str(tmp_path))
+    assert res.returncode == 2 and "WORLD_SIZE" in res.stderr
