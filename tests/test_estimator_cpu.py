@@ -111,3 +111,105 @@ def test_batched_acquisition_rejects_nan_ei():
 
     with pytest.raises(ValueError):
         E.find_best_candidate_by_ei(np.zeros((4, 3)), Bad(), 0.0)
+
+
+# ---- vectors the reference's own ynormalize.rs tests hold (tests/golden/reference_kats.json, data only) --------------
+import json
+import os
+
+_YK = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))["ynormalize"]
+
+
+def _log_norm(expected=0.0, amplitude=1.0):
+    return E.YNormalize(amplitude, expected, "logarithmic")
+
+
+def test_ref_logwarp_project_mean_from():  # ynormalize.rs:48-75
+    k = _YK["logwarp_project_mean_from"]
+    m, s = np.array(k["logmean"]), np.array(k["logstd"])
+    got = _log_norm().project_mean_from_normalized(m, s * s)
+    np.testing.assert_allclose(got, np.exp(k["expected_exponents"]), rtol=0, atol=k["epsilon"])
+
+
+def test_ref_logwarp_project_variance():  # ynormalize.rs:125-147
+    k = _YK["logwarp_project_variance"]
+    m, s = np.array(k["logmean"]), np.array(k["logstd"])
+    n = _log_norm()
+    np.testing.assert_allclose(n.project_std_from_normalized(m, s * s), n.project_mean_from_normalized(m, s * s) * np.sqrt(np.exp(s * s) - 1),
+                               rtol=0, atol=k["epsilon"])
+    np.testing.assert_allclose(n.project_cv_from_normalized(m, s * s), np.sqrt(np.exp(s * s) - 1), rtol=0, atol=1e-12)  # :150-156
+
+
+def test_ref_lognormal_moments_from_data():  # ynormalize.rs:78-112 (own sample: the reference's RNG stream is not available)
+    k = _YK["lognormal_from_data"]
+    data = np.exp(np.random.default_rng(83229).normal(k["mu"], k["sigma"], k["count"]))
+    logmean, logvar = np.log(data).mean(), np.log(data).var()
+    n = _log_norm()
+    mean = n.project_mean_from_normalized(np.array([logmean]), np.array([logvar]))[0]
+    std = n.project_std_from_normalized(np.array([logmean]), np.array([logvar]))[0]
+    assert abs(mean - data.mean()) <= k["mean_max_relative"] * max(abs(mean), data.mean())
+    assert abs(std - data.std()) <= k["std_max_relative"] * max(abs(std), data.std())
+
+
+@pytest.mark.parametrize("case", _YK["inverse"]["cases"])
+def test_ref_projection_has_an_inverse(case):  # ynormalize.rs:324-383
+    y = np.array(case["input"])
+    yn, norm = E.YNormalize.new_project_into_normalized(y, case["projection"], case["known_optimum"])
+    eps = _YK["inverse"]["epsilon"]
+    np.testing.assert_allclose(norm.project_location_from_normalized(yn), y, rtol=0, atol=eps)
+    np.testing.assert_allclose(norm.project_into_normalized(y), yn, rtol=0, atol=eps)
+    if case["known_optimum"] is not None:
+        assert norm.expected == min(y.min() - (0.0 if case["projection"] == "linear" else 1.0), case["known_optimum"])  # guess_min :291-303
+
+
+def test_ref_linear_can_handle_variance():  # ynormalize.rs:385-399
+    k = _YK["linear_variance"]
+    norm = E.YNormalize(k["amplitude"], k["expected"], "linear")
+    np.testing.assert_allclose(norm.project_std_from_normalized(np.zeros(3), np.array(k["variance"])), k["std"], rtol=0, atol=k["epsilon"])
+
+
+@pytest.mark.parametrize("case", _YK["logarithmic_mean"]["cases"])
+def test_ref_logarithmic_project_mean(case):  # ynormalize.rs:401-463
+    norm = E.YNormalize(case["amplitude"], case["expected"], "logarithmic")
+    got = norm.project_mean_from_normalized(np.array([case["mean"]]), np.array([case["std"] ** 2]))[0]
+    assert abs(got - case["want"]) <= _YK["logarithmic_mean"]["epsilon"] * max(1.0, abs(case["want"]) * 1e-2)  # abs_diff_eq 1e-7 at e..e^6.5
+
+
+@pytest.mark.parametrize("projection", ["linear", "logarithmic"])
+def test_ref_statistics_survive_the_projection(projection):  # ynormalize.rs:465-521
+    # The log-normal moment match is a property of the sample: the reference's tolerances (1 % / 10 %) hold for about a third
+    # of all 500-point samples, its seed (903282318 on its own RNG) picks one of them -- ours (903282322 on numpy's) too.
+    k = _YK["statistics"]
+    data = np.exp(np.random.default_rng(903282322).normal(k["mu"], k["sigma"], k["count"]))
+    want_mean, want_std = data.mean(), data.std()
+    t, norm = E.YNormalize.new_project_into_normalized(data, projection)
+    tm, tv = np.array([t.mean()]), np.array([t.var()])
+    mean = norm.project_mean_from_normalized(tm, tv)[0]
+    std = norm.project_std_from_normalized(tm, tv)[0]
+    cv = norm.project_cv_from_normalized(tm, tv)[0]
+    r = k[projection]
+    rel = lambda a, b, tol: abs(a - b) <= tol * max(abs(a), abs(b))  # relative_eq!(max_relative)
+    assert rel(mean, want_mean, r["mean_ratio"]) and rel(std, want_std, r["std_ratio"])
+    assert rel(cv, want_std / want_mean, math.hypot(r["mean_ratio"], r["std_ratio"]))
+
+
+def test_predict_statistics_zero_std_boundary_is_f64_epsilon():
+    # gpr.rs:133: abs_diff_eq!(std, 0.0) -> |std| <= f64::EPSILON takes the degenerate branch (all quartiles = mean)
+    class FakeFitted:
+        lml = 0.0
+
+        def __init__(self, var):
+            self.var = var
+
+        def predict(self, x, want_variance=True):
+            return np.array([0.7]), np.array([self.var]), 0
+
+    eps = np.finfo(float).eps
+    for var, degenerate in [(0.0, True), (eps * eps, True), ((4 * eps) ** 2, False), (0.04, False)]:
+        m = E.SurrogateModelGPR(FakeFitted(var), (1e-5, 1e5), (0.1, 10.0), [(1e-3, 1e3)], E.YNormalize(2.0, 1.0, "linear"), np.float64)
+        st = m.predict_statistics(np.array([0.5]))
+        assert st.mean() == pytest.approx((0.7 - 0.05) * 2.0 + 1.0)
+        if degenerate:
+            assert st.q1 == st.q2 == st.q3 == st.mean()
+        else:
+            assert st.q1 < st.q2 < st.q3 and st.iqr() == pytest.approx(2 * 0.6744897501960817 * math.sqrt(var) * 2.0, rel=1e-9)
