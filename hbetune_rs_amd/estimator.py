@@ -277,6 +277,65 @@ def acquire_by_mutation(candidates, model, fmin):
     return idx, means[rows, idx], eis[rows, idx]
 
 
+class FitnessOperator:
+    """`FitnessOperator(model, space, fitness_via)` (minimize.rs:653-678) over feature arrays.  The reference predicts the
+    mean of ONE individual per `get_fitness` call -- twice per comparison inside `sort_by` / `select_next_population`
+    (minimize.rs:509-514, 566-575), each an O(n^2) single-point predict.  Here the fitness of a whole population is ONE
+    batched `predict_mean_a`; comparisons then run on the cached values with the same `partial_cmp` semantics."""
+
+    def __init__(self, model, fitness_via="prediction"):
+        if fitness_via not in ("prediction", "observation"):
+            raise ValueError(fitness_via)
+        self.model, self.fitness_via = model, fitness_via
+
+    def get_fitness(self, features, observations=None):
+        """fitness of every individual: predicted mean at its features, or its observation (minimize.rs:657-668)."""
+        if self.fitness_via == "prediction":
+            return np.asarray(self.model.predict_mean_a(np.asarray(features)))
+        if observations is None:
+            raise ValueError("individual has no observation")
+        return np.asarray(observations)
+
+    @staticmethod
+    def compare(fa, fb):
+        """`a.partial_cmp(&b)` (minimize.rs:670-677): -1 / 0 / 1, or None when not comparable (NaN)."""
+        if math.isnan(fa) or math.isnan(fb):
+            return None
+        return int(fa > fb) - int(fa < fb)
+
+    def sort_population(self, features, observations=None):
+        """indices of the population sorted by fitness, best (lowest) first: `population.sort_by(compare)` in
+        `resize_population` (minimize.rs:509-514; Rust's sort_by is stable).  Raises where the reference panics."""
+        f = self.get_fitness(features, observations)
+        if np.isnan(f).any():
+            raise ValueError("individuals are comparable")
+        return np.argsort(f, kind="stable"), f
+
+    def select_next_population(self, parent_features, offspring_features, parent_obs=None, offspring_obs=None):
+        """`select_next_population` (minimize.rs:722-747): each offspring competes against its one parent and is kept unless
+        `compare(parent, offspring) == Some(Less)` (so an incomparable pair keeps the offspring).  Returns a boolean array:
+        True where the offspring is selected.  Two batched predicts for the whole generation."""
+        fp = self.get_fitness(parent_features, parent_obs)
+        fo = self.get_fitness(offspring_features, offspring_obs)
+        with np.errstate(invalid="ignore"):
+            return ~(fp < fo)
+
+
+def find_best_individual_by_confidence_bound(features, model, confidence_bound):
+    """minimize.rs:680-714 over a feature array: the individual with the lowest confidence bound (the FIRST of several
+    minimal ones: the reference replaces its suggestion only on a strictly lower bound) and the predicted mean there.  One
+    batched `predict_confidence_bound_a` + one `predict_mean` instead of one single-point predict per individual."""
+    features = np.asarray(features)
+    if features.ndim != 2 or features.shape[0] < 1:
+        raise ValueError("should have at least one individual")
+    ucb = np.asarray(model.predict_confidence_bound_a(features, confidence_bound))
+    best = 0
+    for i in range(1, len(ucb)):
+        if ucb[i] < ucb[best]:
+            best = i
+    return best, model.predict_mean(features[best])
+
+
 class EstimatorGPR:
     """gpr.rs:215-400: defaults, builders, estimate(), extend()."""
 

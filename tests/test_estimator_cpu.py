@@ -213,3 +213,74 @@ def test_predict_statistics_zero_std_boundary_is_f64_epsilon():
             assert st.q1 == st.q2 == st.q3 == st.mean()
         else:
             assert st.q1 < st.q2 < st.q3 and st.iqr() == pytest.approx(2 * 0.6744897501960817 * math.sqrt(var) * 2.0, rel=1e-9)
+
+
+# ---- batched forms of the caller's scalar-predict loops, host logic on a fake model ---------------
+class _CbModel:
+    """mean = first feature, std = second feature (no GPU needed)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def predict_mean_a(self, x):
+        self.calls.append(("mean_a", len(x)))
+        return np.asarray(x)[:, 0].copy()
+
+    def predict_mean(self, x):
+        self.calls.append(("mean", 1))
+        return float(np.asarray(x)[0])
+
+    def predict_confidence_bound(self, x, cb):
+        self.calls.append(("cb", 1))
+        return float(x[0] + cb * x[1])
+
+    def predict_confidence_bound_a(self, x, cb):
+        self.calls.append(("cb_a", len(x)))
+        x = np.asarray(x)
+        return x[:, 0] + cb * x[:, 1]
+
+
+def test_find_best_individual_by_confidence_bound_matches_the_reference_loop():
+    rng = np.random.default_rng(4)
+    feats = np.round(rng.random((40, 2)), 1)  # coarse values: ties
+    for cb in (-1.0, 0.0, 2.0):
+        m = _CbModel()
+        got_i, got_y = E.find_best_individual_by_confidence_bound(feats, m, cb)
+        assert [c[0] for c in m.calls] == ["cb_a", "mean"]  # one batched predict + the final mean
+        # minimize.rs:680-714, literally
+        ref = _CbModel()
+        sug, sug_ucb = 0, ref.predict_confidence_bound(feats[0], cb)
+        for i in range(1, len(feats)):
+            c = ref.predict_confidence_bound(feats[i], cb)
+            if c < sug_ucb:
+                sug, sug_ucb = i, c
+        assert got_i == sug and got_y == ref.predict_mean(feats[sug])
+    with pytest.raises(ValueError):
+        E.find_best_individual_by_confidence_bound(np.zeros((0, 2)), _CbModel(), 1.0)
+
+
+def test_fitness_operator_batched_sort_and_selection():
+    rng = np.random.default_rng(9)
+    feats = np.round(rng.random((30, 2)), 1)
+    obs = np.round(rng.random(30), 1)
+    m = _CbModel()
+    op = E.FitnessOperator(m, "prediction")
+    order, f = op.sort_population(feats)
+    assert m.calls == [("mean_a", 30)]
+    # the reference: population.sort_by(|a, b| fitness.compare(a, b)) with a stable sort (minimize.rs:509-514)
+    import functools
+
+    ref = sorted(range(30), key=functools.cmp_to_key(lambda a, b: E.FitnessOperator.compare(feats[a, 0], feats[b, 0])))
+    assert order.tolist() == ref
+    order_o, _ = E.FitnessOperator(m, "observation").sort_population(feats, obs)
+    assert order_o.tolist() == sorted(range(30), key=lambda i: (obs[i], i))
+    # select_next_population (minimize.rs:722-747): parent kept only when strictly better; NaN keeps the offspring
+    parents, offspring = feats[:15], feats[15:].copy()
+    offspring[3, 0] = np.nan
+    keep_off = op.select_next_population(parents, offspring)
+    for i in range(15):
+        cmp = E.FitnessOperator.compare(parents[i, 0], offspring[i, 0])
+        assert keep_off[i] == (cmp != -1)
+    with pytest.raises(ValueError):
+        op.sort_population(offspring)  # NaN fitness: "individuals are comparable" panics in the reference
+    assert E.FitnessOperator.compare(1.0, float("nan")) is None

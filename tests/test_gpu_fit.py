@@ -177,6 +177,16 @@ def test_incremental_extend_matches_the_full_path(n0, n, dtype):
     mf, vf, _ = full.predict(Xs)
     np.testing.assert_allclose(mi, mf, rtol=0, atol=tol * max(1.0, np.abs(mf).max()))
     np.testing.assert_allclose(vi, vf, rtol=0, atol=tol * math.exp(theta[1]))
+    # ... and as the ORACLE's FittedKernel::extend from scratch (fit.rs:33-68) + predict (predict.rs:7-52), f64 arithmetic
+    s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+    ref = O.extend(X.astype(np.float64), y.astype(np.float64), s2, c, ell, 2.5)
+    otol = 1e-8 if dtype == np.float64 else 2e-4
+    assert abs(inc.lml - ref["lml"]) <= otol * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(ai, ref["alpha"], rtol=0, atol=otol * max(1.0, np.abs(ref["alpha"]).max()))
+    np.testing.assert_allclose(ki, ref["k_inv"], rtol=0, atol=otol * np.abs(ref["k_inv"]).max())
+    rm, rv, _ = O.predict(Xs.astype(np.float64), X.astype(np.float64), ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    np.testing.assert_allclose(mi, rm, rtol=0, atol=otol * max(1.0, np.abs(rm).max()))
+    np.testing.assert_allclose(vi, np.maximum(rv, 0.0), rtol=0, atol=otol * c)
     # a chain of incremental extends stays consistent
     if n - n0 > 20:
         mid = prior.extend_with(X[: n0 + 10], y[: n0 + 10])
