@@ -99,6 +99,31 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 #pragma unroll
     for (int b = 0; b < TMB; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
 
+  // f32: fp64 totals per F32_CHUNK contraction elements, exactly as gemm_kernel does (same chunk boundaries: same bits)
+  constexpr bool CHUNKED = sizeof(T) == 4;
+  static_assert(!CHUNKED || BK == F32_CHUNK, "one stage = one accumulation chunk");
+  double tot[CHUNKED ? TMA : 1][CHUNKED ? TMB : 1][4];
+  if constexpr (CHUNKED) {
+#pragma unroll
+    for (int a = 0; a < TMA; ++a)
+#pragma unroll
+      for (int b = 0; b < TMB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[a][b][r] = 0.0;
+  }
+  auto flush = [&]() {
+    if constexpr (CHUNKED) {
+#pragma unroll
+      for (int a = 0; a < TMA; ++a)
+#pragma unroll
+        for (int b = 0; b < TMB; ++b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[a][b][r] += (double)acc[a][b][r];
+          acc[a][b] = acc_t{0, 0, 0, 0};
+        }
+    }
+  };
+
   const int soA = akm ? 1 : SK, skA = akm ? SMA : 1;
   const int soB = bkm ? 1 : SK, skB = bkm ? SMB : 1;
   const int fa0 = (wm * (TA / G::WM) + (lane & 15)) * soA + (lane >> 4) * skA;
@@ -140,6 +165,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
     __builtin_amdgcn_sched_group_barrier(0x100, TMA + TMB, 0);  // reads first: their latency hides under the MFMAs
     __builtin_amdgcn_sched_group_barrier(0x008, TMA * TMB, 0);
     __builtin_amdgcn_sched_barrier(0);
+    flush();
   };
   if (nstages > 0) {
     load_stage(ra0, rb0);
@@ -169,7 +195,9 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
       for (int r = 0; r < 4; ++r) {
         const int row = er0 + a * 16 + C::crow(lane, r);
         T* p = Cg + (size_t)row * ld + ec0 + b * 16;
-        T v = acc[a][b][r];
+        T v;
+        if constexpr (CHUNKED) v = (T)tot[a][b][r];
+        else v = acc[a][b][r];
         if (neg) v = -v;
         if (accum) v += *p;
         gstore<true>(p, v);

@@ -118,9 +118,10 @@ void launch_gemm(const GemmLaunch& g, int tile, hipStream_t s);  // tile in {32,
 template <typename T>
 void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s);
 
-// Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag.
+// Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag;
+// W3 (optional): the lower triangle of L_blk itself.
 template <typename T>
-void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg = 0);
+void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg = 0, T* W3 = nullptr);
 
 // alpha = X^T (X y), lml pieces.  X lower-triangular np x np in W2.  part: [np/256][np] scratch.
 template <typename T>
@@ -144,6 +145,13 @@ template <typename T>
 void launch_pred_mean(const T* Ks, int m, int np, const T* alpha, T* mean, hipStream_t s);
 template <typename T>
 void launch_pred_var(const T* Ks, const T* Q, int m, int np, const EvalParams* P, T* var, EvalOut* out, hipStream_t s);
+
+// predict for m <= PRED_SMALL_MAX candidates without the 128-row padding: reads L^-1 once (row dots against the m
+// cross-kernel vectors).  Ks: [PRED_SMALL_MAX][np] scratch, pmean: [(np+255)/256][PRED_SMALL_MAX], w: [n][PRED_SMALL_MAX].
+constexpr int PRED_SMALL_MAX = 16;
+template <typename T>
+void launch_predict_small(const T* Xs, int m, const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* alpha, const T* Linv,
+                          T* Ks, double* pmean, double* w, int want_var, T* mean, T* var, int* n_warn, hipStream_t s);
 
 void launch_set_info(int* info, int value, hipStream_t s);
 // start of an evaluation: info = n_warn = done = 0, lml and gradient poisoned with NaN (a launch that was rejected or

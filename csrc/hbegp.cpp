@@ -288,6 +288,7 @@ struct Slot {
   int dev = 0;
   hipStream_t stream = nullptr;
   T *W1 = nullptr, *W2 = nullptr, *Kinv[2] = {nullptr, nullptr}, *alpha[2] = {nullptr, nullptr};
+  T* W3 = nullptr;  // f32 problems only: the Cholesky factor L (lower), kept for the refinement of the panel solves
   T *ldiag = nullptr, *wbuf = nullptr;
   double *part_t = nullptr, *part_g = nullptr;
   EvalParams* dP = nullptr;
@@ -331,6 +332,11 @@ struct Problem : ProblemBase {
   std::vector<DagTask> dag_host_tasks;      // kept for the trace dump
   size_t dag_ctrl_bytes = 0;
   double dag_gflop = 0;
+  // f32 (--use-32): the panel solve T = A21 L11^-T is a product with the explicit inverse X11, whose residual grows with
+  // cond(L11) * eps -- harmless in f64, but in f32 it makes the lml gradient ~8x less accurate than LAPACK's substitution.
+  // One step of iterative refinement against the factor itself (kept in W3) restores a small residual:
+  //   T = A21 X11^T;  A21 -= T L11^T;  T += A21 X11^T          (three products of the same shape, all fp32 MFMA)
+  bool refine_ = false;
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
 
@@ -349,6 +355,10 @@ struct Problem : ProblemBase {
     ctx = c; n = n_; d = d_; np = round_up(n_, NB); n_slots = n_slots_;
     nu2 = (int)std::lround(2 * nu);
     is_f32 = sizeof(T) == 4;
+    // off by default: with the chunked fp64 totals of the f32 tile GEMM (kernels.hip) the plain recursion is already 2-7x
+    // closer to the f64 result than LAPACK's f32 path (n=2048, cond 7e4: gradient 3e-6 vs 2e-5); refinement buys another
+    // 1.3x on alpha / K^-1 for 26 % more time (measured), for kernel matrices beyond cond ~1e5
+    refine_ = is_f32 && env_int("HBEGP_F32_REFINE", 0) != 0;
     const size_t nn = (size_t)np * np;
     Xd.assign(c->devs.size(), nullptr);
     yd.assign(c->devs.size(), nullptr);
@@ -376,6 +386,11 @@ struct Problem : ProblemBase {
         // once per slot is enough -- also when it is recycled from the pool (it may have held a full symmetric K^-1).
         // W1's strict upper part is only ever multiplied by those zeros or ignored: it just has to be finite.
         HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
+        if (refine_) {
+          bool f3 = false;
+          s.W3 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &f3));
+          HIPCHECK(hipMemset(s.W3, 0, sizeof(T) * nn));  // strict upper triangle must be zero, like W2's
+        }
         (void)fresh1; (void)fresh2; (void)fk;  // fresh blocks were cleared by the pool
         HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
         HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));
@@ -399,6 +414,7 @@ struct Problem : ProblemBase {
     // HBEGP_DAG=0/1 forces it (read per problem: the parity tests flip it inside one process).
     const int dag_env = env_int("HBEGP_DAG", -1);
     dag_ = (dag_env < 0 ? n_slots >= 2 : dag_env != 0) && !adhoc_ && np / NB >= 2;
+    if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
       int cus = 256;
       {
@@ -462,7 +478,7 @@ struct Problem : ProblemBase {
           for (int b = 0; b < 2; ++b)
             if (s.graph[a][b]) (void)hipGraphExecDestroy(s.graph[a][b]);
         const size_t nnb = sizeof(T) * (size_t)np * np;
-        g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb);
+        g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb); g_pool.put(s.dev, s.W3, nnb);
         for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
         (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
         (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace);
@@ -532,7 +548,7 @@ struct Problem : ProblemBase {
     if (hi - lo == 1) {
       if (dry_) return;
       if (tm) tm->begin(PhaseTimer::LEAF);
-      launch_leaf<T>(s.W1, s.W2, np, lo, s.ldiag, &s.dOut->info, s.stream);
+      launch_leaf<T>(s.W1, s.W2, np, lo, s.ldiag, &s.dOut->info, s.stream, 0, refine_ ? s.W3 : nullptr);
       if (tm) tm->end();
       return;
     }
@@ -545,17 +561,35 @@ struct Problem : ProblemBase {
     if (!left_done) chol_inv_rec(s, di, lo, mid, tm);
     GemmOp base{};
     base.lda = base.ldb = base.ldc = np;
+    T* Tbuf = refine_ ? s.W3 : s.W2;  // where T = L21 lives: f32 keeps it (it IS the factor's block), f64 lets X21 overwrite it
     {
-      // T = A21 * X11^T  -> W2[2,1]      (TRSM of potrf as a product with the explicit inverse)
+      // T = A21 * X11^T  -> Tbuf[2,1]      (TRSM of potrf as a product with the explicit inverse)
       GemmLaunch g{};
       g.nops = 1;
       GemmOp& op = g.op[0];
       op = base;
-      op.A = s.W1; op.B = s.W2; op.C = s.W2;
+      op.A = s.W1; op.B = s.W2; op.C = Tbuf;
       op.a_kmajor = 0; op.b_kmajor = 0;
       op.ci0 = mid; op.mi = hi - mid; op.cj0 = lo; op.nj = mid - lo;
       op.k0 = lo; op.k1 = mid; op.klim = 1; op.maskB = 1;
       gemm(s, di, g, tm, PhaseTimer::GEMM);
+      if (refine_ && !left_done) {
+        // residual in place: A21 -= T * L11^T   (L11 = W3[lo:mid, lo:mid], lower), then the correction T += A21 * X11^T
+        GemmLaunch gr{};
+        gr.nops = 1;
+        GemmOp& r = gr.op[0];
+        r = base;
+        r.A = s.W3; r.B = s.W3; r.C = s.W1;
+        r.ci0 = mid; r.mi = hi - mid; r.cj0 = lo; r.nj = mid - lo;
+        r.k0 = lo; r.k1 = mid; r.klim = 1; r.maskB = 1; r.alpha_neg = 1; r.beta_one = 1;
+        gemm(s, di, gr, tm, PhaseTimer::GEMM);
+        GemmLaunch gc{};
+        gc.nops = 1;
+        GemmOp& cc = gc.op[0];
+        cc = op;
+        cc.beta_one = 1;
+        gemm(s, di, gc, tm, PhaseTimer::GEMM);
+      }
     }
     {
       // A22 -= T T^T (lower)   and   U = T * X11 -> W1[2,1]   (independent: one launch, one static schedule).
@@ -565,12 +599,12 @@ struct Problem : ProblemBase {
       g.nops = 2;
       GemmOp& syrk = g.op[0];
       syrk = base;
-      syrk.A = s.W2; syrk.B = s.W2; syrk.C = s.W1;
+      syrk.A = Tbuf; syrk.B = Tbuf; syrk.C = s.W1;
       syrk.ci0 = mid; syrk.cj0 = mid; syrk.mi = hi - mid; syrk.nj = hi - mid; syrk.c_lower = 1;
       syrk.k0 = lo; syrk.k1 = mid; syrk.alpha_neg = 1; syrk.beta_one = 1;
       GemmOp& u = g.op[1];
       u = base;
-      u.A = s.W2; u.B = s.W2; u.C = s.W1;
+      u.A = Tbuf; u.B = s.W2; u.C = s.W1;
       u.a_kmajor = 0; u.b_kmajor = 1;
       u.ci0 = mid; u.mi = hi - mid; u.cj0 = lo; u.nj = mid - lo;
       u.k0 = lo; u.k1 = mid; u.klim = 2; u.maskB = 1;
@@ -612,7 +646,7 @@ struct Problem : ProblemBase {
     static const int big_env = env_int("HBEGP_NBIG", 1 << 20);  // measured at n=4096: 8 -> 3.55 ms, 4 -> 3.56, off (binary recursion only) -> 3.43
     const int big = std::max(1, big_env);
     const int nbb = (nb + big - 1) / big;
-    if (nbb <= 1) {
+    if (nbb <= 1 || refine_) {
       chol_inv_rec(s, di, 0, nb, tm);
       return;
     }
@@ -1041,12 +1075,18 @@ struct hbegp_model {
   // predict scratch (grow-only)
   int cap_m = 0;
   void *Xs = nullptr, *Ks = nullptr, *Q = nullptr, *mean = nullptr, *var = nullptr;
+  // scratch of the path for a handful of candidates (allocated on first use): device [Xs | Ks | out], partial sums, and
+  // pinned host staging so that a single-point predict costs one H2D and one D2H
+  void *sm_Xs = nullptr, *sm_Ks = nullptr, *sm_out = nullptr, *sm_hin = nullptr, *sm_hout = nullptr;
+  double *sm_pmean = nullptr, *sm_w = nullptr;
   std::mutex mu;
   ~hbegp_model() {
     (void)hipSetDevice(dev);
     if (stream) (void)hipStreamSynchronize(stream);
     (void)hipFree(X); (void)hipFree(alpha); (void)hipFree(ldiag); g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
     (void)hipFree(Xs); (void)hipFree(Ks); (void)hipFree(Q); (void)hipFree(mean); (void)hipFree(var);
+    (void)hipFree(sm_Xs); (void)hipFree(sm_Ks); (void)hipFree(sm_out); (void)hipFree(sm_pmean); (void)hipFree(sm_w);
+    (void)hipHostFree(sm_hin); (void)hipHostFree(sm_hout);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -1093,6 +1133,38 @@ template <typename T>
 static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, int* n_warn) {
   std::lock_guard<std::mutex> lock(m->mu);
   HIPCHECK(hipSetDevice(m->dev));
+  static const bool small_on = env_int("HBEGP_PRED_SMALL", 1) != 0;
+  static const bool kinv_form_small = env_int("HBEGP_PREDVAR_KINV", 0) != 0;
+  if (small_on && cnt <= PRED_SMALL_MAX && !kinv_form_small) {
+    // a handful of candidates (the caller's scalar predict_* loops): read L^-1 once instead of a padded 128-row tile GEMM
+    const size_t out_bytes = sizeof(T) * 2 * PRED_SMALL_MAX + 16;
+    if (!m->sm_Xs) {
+      HIPCHECK(hipMalloc(&m->sm_Xs, sizeof(T) * PRED_SMALL_MAX * m->d));
+      HIPCHECK(hipMalloc(&m->sm_Ks, sizeof(T) * (size_t)PRED_SMALL_MAX * m->np));
+      HIPCHECK(hipMalloc(&m->sm_out, out_bytes));
+      HIPCHECK(hipMalloc(&m->sm_pmean, sizeof(double) * (size_t)((m->np + 255) / 256) * PRED_SMALL_MAX));
+      HIPCHECK(hipMalloc(&m->sm_w, sizeof(double) * (size_t)m->n * PRED_SMALL_MAX));
+      HIPCHECK(hipHostMalloc(&m->sm_hin, sizeof(T) * PRED_SMALL_MAX * m->d, hipHostMallocDefault));
+      HIPCHECK(hipHostMalloc(&m->sm_hout, out_bytes, hipHostMallocDefault));
+    }
+    hipStream_t s = m->stream;
+    memcpy(m->sm_hin, Xs, sizeof(T) * (size_t)cnt * m->d);
+    HIPCHECK(hipMemcpyAsync(m->sm_Xs, m->sm_hin, sizeof(T) * (size_t)cnt * m->d, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(m->sm_out, 0, out_bytes, s));
+    T* dmean = static_cast<T*>(m->sm_out);
+    T* dvar = dmean + PRED_SMALL_MAX;
+    int* dwarn = reinterpret_cast<int*>(dvar + PRED_SMALL_MAX);
+    launch_predict_small<T>(static_cast<T*>(m->sm_Xs), cnt, static_cast<T*>(m->X), m->n, m->d, m->np, m->nu2, m->dP, static_cast<T*>(m->alpha),
+                            static_cast<T*>(m->Xinv), static_cast<T*>(m->sm_Ks), m->sm_pmean, m->sm_w, var ? 1 : 0, dmean, dvar, dwarn, s);
+    CHECK_LAUNCHES();
+    HIPCHECK(hipMemcpyAsync(m->sm_hout, m->sm_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    const T* hmean = static_cast<const T*>(m->sm_hout);
+    memcpy(mean, hmean, sizeof(T) * cnt);
+    if (var) memcpy(var, hmean + PRED_SMALL_MAX, sizeof(T) * cnt);
+    if (n_warn) *n_warn = var ? *reinterpret_cast<const int*>(hmean + 2 * PRED_SMALL_MAX) : 0;
+    return HBEGP_OK;
+  }
   const int mp = round_up(std::max(cnt, 1), NB);
   if (mp > m->cap_m) {
     (void)hipFree(m->Xs); (void)hipFree(m->Ks); (void)hipFree(m->Q); (void)hipFree(m->mean); (void)hipFree(m->var);

@@ -71,6 +71,8 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 // =================================================================================================================
 // Tile GEMM
 // =================================================================================================================
+constexpr int F32_CHUNK = 32;  // contraction elements per f32 accumulation chunk (see gemm_kernel)
+
 template <typename T, int TILE, int KM = 0>
 struct GemmGeom {
   using C = Cfg<T>;
@@ -224,6 +226,33 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+  // f32 only: the MFMA accumulates in f32, and a long sum of products of one sign (the diagonals of T T^T and X^T X) loses
+  // every term below half an ulp of the running sum -- a systematic loss, measured as a -2e-4 relative bias of K^-1 at
+  // n=2048, cond 7e4 (LAPACK f32: -4e-5).  Every F32_CHUNK contraction elements the accumulators are added to fp64 totals
+  // and cleared (chunk 32: bias -3e-6 in a host emulation).  Chunk boundaries are absolute multiples of F32_CHUNK, so every
+  // tile size, and the task-queue kernel, produce the same bits.
+  constexpr bool CHUNKED = sizeof(T) == 4;
+  double tot[CHUNKED ? TM : 1][CHUNKED ? TM : 1][4];
+  if constexpr (CHUNKED) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[a][b][r] = 0.0;
+  }
+  auto flush = [&]() {
+    if constexpr (CHUNKED) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[a][b][r] += (double)acc[a][b][r];
+          acc[a][b] = acc_t{0, 0, 0, 0};
+        }
+    }
+  };
 
   // fragment addressing: element (outer index o, contraction k) at o*so + k*sk
   const int soA = akm ? 1 : SK, skA = akm ? SM : 1;
@@ -259,6 +288,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       if (k4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);
       if (k4 + 1 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
+      if (CHUNKED && ((k4 + 1) * 4) % F32_CHUNK == 0) flush();
     }
   };
 
@@ -323,6 +353,8 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);  // reads first: their latency hides under the MFMAs
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
       __builtin_amdgcn_sched_barrier(0);
+      static_assert(!CHUNKED || BK == F32_CHUNK, "f32 64-tile: one stage = one accumulation chunk");
+      flush();
     };
     if (nstages > 0) {
       load_stage(ra0, rb0);
@@ -405,7 +437,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + a * 16 + C::crow(lane, r);
         T* p = Cg + (size_t)row * op.ldc + col0 + b * 16;
-        T v = acc[a][b][r];
+        T v;
+        if constexpr (CHUNKED) v = (T)tot[a][b][r];
+        else v = acc[a][b][r];
         if (op.alpha_neg) v = -v;
         if (op.beta_one) v += *p;
         *p = v;
@@ -491,7 +525,8 @@ __device__ __forceinline__ void gstore(TIO* p, TIO v) {
 
 template <typename T, typename TIO, bool SC1>
 __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
-                                          TIO* __restrict__ ldiag, int* info, int dbg, char* smem_raw) {
+                                          TIO* __restrict__ ldiag, int* info, int dbg, char* smem_raw,
+                                          TIO* __restrict__ W3 = nullptr) {
   using C = Cfg<T>;
   using L = LeafGeom<T>;
   using acc_t = typename C::acc_t;
@@ -705,22 +740,30 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
     gstore<SC1>(&Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j], (TIO)Ys[pblk * YB + r * YS + j]);
   }
+  // optional: the factor itself (lower triangle of the block), for the f32 path's refinement of the panel solve
+  if (W3) {
+    TIO* Lblk = W3 + g0;
+    for (int c = t; c < 128 * 128; c += 512) {
+      const int r = c >> 7, j = c & 127;
+      if (j <= r) gstore<SC1>(&Lblk[(size_t)r * ld + j], (TIO)As[r * S + j]);
+    }
+  }
 }
 
 template <typename T, typename TIO>
 __global__ void __launch_bounds__(512, 2) leaf_kernel(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
-                                                   TIO* __restrict__ ldiag, int* info, int dbg) {
+                                                   TIO* __restrict__ ldiag, int* info, int dbg, TIO* __restrict__ W3) {
   if (*info != 0) return;
   extern __shared__ __align__(16) char smem_raw[];
-  leaf_body<T, TIO, false>(W1, W2, ld, blk, ldiag, info, dbg, smem_raw);
+  leaf_body<T, TIO, false>(W1, W2, ld, blk, ldiag, info, dbg, smem_raw, W3);
 }
 
 template <typename T>
-void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg) {
-  hipLaunchKernelGGL((leaf_kernel<double, T>), dim3(1), dim3(512), LeafGeom<double>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg);
+void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t s, int dbg, T* W3) {
+  hipLaunchKernelGGL((leaf_kernel<double, T>), dim3(1), dim3(512), LeafGeom<double>::LDS_BYTES, s, W1, W2, ld, blk, ldiag, info, dbg, W3);
 }
-template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t, int);
-template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t, int);
+template void launch_leaf<double>(double*, double*, int, int, double*, int*, hipStream_t, int, double*);
+template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStream_t, int, float*);
 
 // =================================================================================================================
 // Kernel-matrix assembly
@@ -1244,6 +1287,114 @@ void launch_pred_var(const T* Ks, const T* Q, int m, int np, const EvalParams* P
 }
 template void launch_pred_var<double>(const double*, const double*, int, int, const EvalParams*, double*, EvalOut*, hipStream_t);
 template void launch_pred_var<float>(const float*, const float*, int, int, const EvalParams*, float*, EvalOut*, hipStream_t);
+
+// =================================================================================================================
+// predict for a handful of candidates (m <= PRED_SMALL_MAX): the caller's acquisition and selection loops issue
+// thousands of single-point predicts per generation (acquisition.rs:46-64, minimize.rs:656-714).  The batched path pads
+// to 128 candidate rows and runs a tile GEMM over all of L^-1 (0.2 ms at n=4096 whatever m is); here L^-1 is read once,
+// row by row, against the m cross-kernel vectors:
+//   kstar_small:  Ks[q][j] = c * Matern(x*_q, x_j)  (same arithmetic as kstar_kernel), partial sums of Ks[q][j] alpha_j
+//   rowdot_small: w[i][q] = sum_{j<=i} Linv[i][j] Ks[q][j]          one wave per row, fp64 accumulation
+//   finish_small: mean_q = sum partials; var_q = c + 1e-5 - sum_i w[i][q]^2, clamp, warning count   (predict.rs:18-48)
+// All sums run in a fixed order: results are bitwise reproducible.
+// =================================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) kstar_small_kernel(const T* __restrict__ Xs, int m, const T* __restrict__ X, int n, int d, int np,
+                                                          int nu2, const EvalParams* __restrict__ P, const T* __restrict__ alpha,
+                                                          T* __restrict__ Ks, double* __restrict__ pmean) {
+  __shared__ double red[4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const T amp = (T)P->amp;
+  for (int q = 0; q < m; ++q) {
+    T v = T(0);
+    if (j < n) {
+      T acc = T(0);
+      for (int k = 0; k < d; ++k) {  // cdist accumulation order (matern_kernel.rs:274-278), operands scaled as matern_kernel.rs:50-60
+        const T ell = (T)P->ell[k];
+        const T df = Xs[(size_t)q * d + k] / ell - X[(size_t)j * d + k] / ell;
+        acc += df * df;
+      }
+      v = amp * matern_map<T>(sqrt(acc), nu2);
+    }
+    if (j < np) Ks[(size_t)q * np + j] = v;
+    const double part = block_sum((j < n) ? (double)v * (double)alpha[j] : 0.0, red);
+    if (threadIdx.x == 0) pmean[(size_t)blockIdx.x * PRED_SMALL_MAX + q] = part;
+  }
+}
+
+template <typename T, int MQ>
+__global__ void __launch_bounds__(256) rowdot_small_kernel(const T* __restrict__ Linv, int np, int n, const T* __restrict__ Ks,
+                                                           double* __restrict__ w) {
+  const int lane = threadIdx.x & 63;
+  const int row = n - 1 - (blockIdx.x * 4 + (threadIdx.x >> 6));  // longest rows first
+  if (row < 0) return;
+  double acc[MQ];
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) acc[q] = 0.0;
+  const T* xr = Linv + (size_t)row * np;
+  for (int k = lane; k <= row; k += 64) {
+    const double x = (double)xr[k];
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) acc[q] += x * (double)Ks[(size_t)q * np + k];
+  }
+#pragma unroll
+  for (int q = 0; q < MQ; ++q) {
+    const double s = wave_sum(acc[q]);
+    if (lane == 0) w[(size_t)row * PRED_SMALL_MAX + q] = s;
+  }
+}
+
+// one workgroup; thread q < m finishes candidate q
+template <typename T>
+__global__ void __launch_bounds__(256) finish_small_kernel(const double* __restrict__ pmean, int nblk, const double* __restrict__ w, int n,
+                                                           int m, const EvalParams* __restrict__ P, int want_var, T* __restrict__ mean,
+                                                           T* __restrict__ var, int* __restrict__ n_warn) {
+  __shared__ double part[PRED_SMALL_MAX][17];
+  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;  // 16 slices of the rows per candidate
+  double s = 0.0;
+  if (want_var && q < m)
+    for (int i = sl; i < n; i += 16) {
+      const double v = w[(size_t)i * PRED_SMALL_MAX + q];
+      s += v * v;
+    }
+  part[q][sl] = s;
+  __syncthreads();
+  if (threadIdx.x < m) {
+    const int c = threadIdx.x;
+    double mu = 0.0;
+    for (int b = 0; b < nblk; ++b) mu += pmean[(size_t)b * PRED_SMALL_MAX + c];
+    mean[c] = (T)mu;
+    if (want_var) {
+      double ss = 0.0;
+      for (int k = 0; k < 16; ++k) ss += part[c][k];
+      const T min_noise = (T)1e-5;
+      T v = (T)P->amp + min_noise - (T)ss;  // predict.rs:25-37
+      if (v < -sqrt(min_noise)) atomicAdd(n_warn, 1);
+      if (v < T(0)) v = T(0);
+      var[c] = v;
+    }
+  }
+}
+
+template <typename T>
+void launch_predict_small(const T* Xs, int m, const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* alpha, const T* Linv,
+                          T* Ks, double* pmean, double* w, int want_var, T* mean, T* var, int* n_warn, hipStream_t s) {
+  const int nblk = (np + 255) / 256;
+  hipLaunchKernelGGL((kstar_small_kernel<T>), dim3(nblk), dim3(256), 0, s, Xs, m, X, n, d, np, nu2, P, alpha, Ks, pmean);
+  if (want_var) {
+    const dim3 grid((n + 3) / 4), block(256);
+    if (m <= 1) hipLaunchKernelGGL((rowdot_small_kernel<T, 1>), grid, block, 0, s, Linv, np, n, Ks, w);
+    else if (m <= 2) hipLaunchKernelGGL((rowdot_small_kernel<T, 2>), grid, block, 0, s, Linv, np, n, Ks, w);
+    else if (m <= 4) hipLaunchKernelGGL((rowdot_small_kernel<T, 4>), grid, block, 0, s, Linv, np, n, Ks, w);
+    else if (m <= 8) hipLaunchKernelGGL((rowdot_small_kernel<T, 8>), grid, block, 0, s, Linv, np, n, Ks, w);
+    else hipLaunchKernelGGL((rowdot_small_kernel<T, 16>), grid, block, 0, s, Linv, np, n, Ks, w);
+  }
+  hipLaunchKernelGGL((finish_small_kernel<T>), dim3(1), dim3(256), 0, s, pmean, nblk, w, n, m, P, want_var, mean, var, n_warn);
+}
+template void launch_predict_small<double>(const double*, int, const double*, int, int, int, int, const EvalParams*, const double*, const double*,
+                                           double*, double*, double*, int, double*, double*, int*, hipStream_t);
+template void launch_predict_small<float>(const float*, int, const float*, int, int, int, int, const EvalParams*, const float*, const float*,
+                                          float*, double*, double*, int, float*, float*, int*, hipStream_t);
 
 // Per-device one-time setup: kernels that use more than 64 KiB of dynamic LDS need the attribute raised.  Called from
 // hbegp_ctx_create() for every device, before any stream capture.

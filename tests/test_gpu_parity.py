@@ -135,13 +135,12 @@ def test_all_matern_orders(nu):
 
 
 def test_f32_path_himmelblau():
-    # C5 (f32, --use-32) at a size the oracle finishes quickly.  Bar: 1e-4 relative to scale against the f64 oracle, or
-    # within 10x of what the reference's own f32 arithmetic (the f32 oracle: LAPACK spotrf/spotri) deviates from f64 --
-    # the reference itself warns its f32 path is unstable (README.md:56-59).
+    # C5 (f32, --use-32) at a size the oracle finishes quickly: the plain 1e-4 bar of the north star against the f64 oracle
+    # (reference arithmetic with A = f64 on the same f32 inputs), no multiples.  The f32 oracle (the reference's own f32
+    # arithmetic: LAPACK spotrf/spotrs/spotri) is shown beside it: the engine must not be further from f64 than that.
     w = synth.make_workload("C5", n=512)
     assert w["X"].dtype == np.float32
-    theta = w["theta"].copy()
-    theta[0] = theta[1] + math.log(0.5)  # keep cond(K) ~ 4e2 so f32 is meaningful
+    theta = w["theta"].copy()  # sigma^2 = 1e-2 c
     s2, c, ell = split_theta(theta)
     X64, y64 = w["X"].astype(np.float64), w["y"].astype(np.float64)
     ref = O.lml_with_gradient(X64, y64, s2, c, ell, 2.5)
@@ -150,17 +149,34 @@ def test_f32_path_himmelblau():
     res = prob.lml_with_gradient(theta)
     assert res is not None
     lml, grad = res
+    alpha, kinv, _ = prob.results()
     gscale = max(1.0, np.abs(ref["grad"]).max())
-    assert abs(lml - ref["lml"]) <= max(F32_TOL * abs(ref["lml"]), 10 * abs(r32["lml"] - ref["lml"]))
-    assert np.abs(grad - ref["grad"]).max() <= max(F32_TOL * gscale, 10 * np.abs(r32["grad"] - ref["grad"]).max())
+    assert abs(lml - ref["lml"]) <= F32_TOL * abs(ref["lml"])
+    assert np.abs(grad - ref["grad"]).max() <= F32_TOL * gscale
+    assert np.abs(alpha - ref["alpha"]).max() <= F32_TOL * np.abs(ref["alpha"]).max()
+    assert np.abs(kinv - ref["k_inv"]).max() <= F32_TOL * np.abs(ref["k_inv"]).max()
+    assert np.abs(grad - ref["grad"]).max() <= 2 * np.abs(r32["grad"] - ref["grad"]).max() + 1e-6 * gscale
     fk = gpr.FittedKernel.extend(w["X"], w["y"], theta)
     Xs = synth.candidates("C5", 64, 2).astype(np.float32)
     mean, var, _ = fk.predict(Xs)
     assert mean.dtype == np.float32 and var.dtype == np.float32
     rmean, rvar, _ = O.predict(Xs.astype(np.float64), X64, ref["alpha"], ref["k_inv"], c, ell, 2.5)
-    m32, v32, _ = O.predict(Xs, w["X"], r32["alpha"], r32["k_inv"], c, ell, 2.5)
-    assert np.abs(mean - rmean).max() <= max(F32_TOL * max(1.0, np.abs(rmean).max()), 10 * np.abs(m32 - rmean).max())
-    assert np.abs(var - rvar).max() <= max(F32_TOL * c, 10 * np.abs(v32 - rvar).max())
+    assert np.abs(mean - rmean).max() <= F32_TOL * max(1.0, np.abs(rmean).max())
+    assert np.abs(var - np.maximum(rvar, 0)).max() <= F32_TOL * c
+    # the f32 fit and the incremental extend against the f64 oracle as well.  The noise floor is raised to 1e-2 c for the
+    # fit: with the default 1e-5 the optimiser walks to cond(K) ~ 1e8, where no f32 arithmetic means anything (the reference
+    # warns about exactly that, README.md:56-59)
+    lo_fit = w["lo"].copy()
+    lo_fit[0] = 1e-2 * c
+    starts = synth.restart_points("C5", lo_fit, w["hi"], 1)
+    fit = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], lo_fit, w["hi"], starts, maxeval=30)
+    f, _, fres = O.objective(fit.theta, X64, y64, 2.5, list(zip(lo_fit, w["hi"])))
+    assert abs(fit.lml + f) <= F32_TOL * max(1.0, abs(f))
+    np.testing.assert_allclose(fit.arrays(False)[0], fres["alpha"], rtol=0, atol=5 * F32_TOL * max(1.0, np.abs(fres["alpha"]).max()))
+    prior = gpr.FittedKernel.extend(w["X"][:400], w["y"][:400], theta)
+    inc = prior.extend_with(w["X"], w["y"])
+    assert inc.incremental and abs(inc.lml - ref["lml"]) <= F32_TOL * abs(ref["lml"])
+    np.testing.assert_allclose(inc.arrays(False)[0], ref["alpha"], rtol=0, atol=F32_TOL * np.abs(ref["alpha"]).max())
 
 
 def test_not_positive_definite_contract():
@@ -236,3 +252,34 @@ def test_invalid_arguments_are_rejected():
     fk = gpr.FittedKernel.extend(X, y + np.arange(8) * 0.1, np.array([math.log(0.1), 0.0, 0.0, 0.0]))
     with pytest.raises(AssertionError):
         fk.predict(np.zeros((3, 5)))  # wrong feature count
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m", [1, 2, 5, 16])
+def test_handful_of_candidates_path_matches_oracle_and_batched_path(m, dtype):
+    # predict.rs:7-52 for m <= 16 runs a dedicated path (L^-1 read once, no 128-row padding): the caller's scalar
+    # predict_mean / predict_mean_ei / predict_confidence_bound loops (acquisition.rs:46-64, minimize.rs:656-714)
+    w = synth.make_workload("C2", n=700)
+    X, y, theta = w["X"].astype(dtype), w["y"].astype(dtype), w["theta"].copy()
+    if dtype == np.float32:
+        theta[0] = theta[1] + math.log(0.5)
+    s2, c, ell = split_theta(theta)
+    fk = gpr.FittedKernel.extend(X, y, theta)
+    Xs = synth.candidates("C2", 40, w["d"]).astype(dtype)
+    ref = O.extend(X.astype(np.float64), y.astype(np.float64), s2, c, ell, 2.5)
+    rm, rv, _ = O.predict(Xs.astype(np.float64), X.astype(np.float64), ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    tol = F64_TOL if dtype == np.float64 else F32_TOL
+    big_mean, big_var, _ = fk.predict(Xs)  # 40 candidates: the batched (tile GEMM) path
+    for start in (0, 7, 24):
+        mean, var, n_warn = fk.predict(Xs[start:start + m])
+        assert mean.dtype == dtype and n_warn == 0
+        np.testing.assert_allclose(mean, rm[start:start + m], rtol=0, atol=tol * max(1.0, np.abs(rm).max()))
+        np.testing.assert_allclose(var, np.maximum(rv[start:start + m], 0), rtol=0, atol=tol * c)
+        np.testing.assert_allclose(mean, big_mean[start:start + m], rtol=0, atol=(1e-12 if dtype == np.float64 else 2e-5) * max(1.0, np.abs(rm).max()))
+        np.testing.assert_allclose(var, big_var[start:start + m], rtol=0, atol=(1e-12 if dtype == np.float64 else 2e-5) * c)
+        mean_only, none, _ = fk.predict(Xs[start:start + m], want_variance=False)
+        assert none is None and np.array_equal(mean_only, mean)
+    # bitwise reproducible
+    a = fk.predict(Xs[:m])
+    b = fk.predict(Xs[:m])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

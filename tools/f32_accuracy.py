@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hbetune_rs_amd import gpr, synth  # noqa: E402
 from oracle import gpr_oracle as O  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-for jit in (0.5, 0.05):
+for jit in (0.5, 0.05, 0.01):
     w = synth.make_workload("C5", n=n)
     theta = w["theta"].copy(); theta[0] = theta[1] + math.log(jit)
     s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])

@@ -11,7 +11,7 @@ t0 = time.perf_counter(); fk = gpr.FittedKernel.extend(w["X"], w["y"], w["theta"
 Xs = synth.candidates(cfg, m, w["d"]).astype(w["X"].dtype)
 fk.predict(Xs)
 out = {"cfg": cfg, "n": w["n"], "dtype": str(w["X"].dtype), "extend_ms": t_ext * 1e3}
-for mm in (1, 32, m):
+for mm in (1, 2, 16, 32, m):
     t0 = time.perf_counter()
     for _ in range(5): fk.predict(Xs[:mm])
     out[f"predict_m{mm}_ms"] = (time.perf_counter() - t0) / 5 * 1e3
