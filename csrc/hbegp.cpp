@@ -1135,7 +1135,8 @@ static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, 
   HIPCHECK(hipSetDevice(m->dev));
   static const bool small_on = env_int("HBEGP_PRED_SMALL", 1) != 0;
   static const bool kinv_form_small = env_int("HBEGP_PREDVAR_KINV", 0) != 0;
-  if (small_on && cnt <= PRED_SMALL_MAX && !kinv_form_small) {
+  static const int small_max = std::min(PRED_SMALL_MAX, std::max(0, env_int("HBEGP_PRED_SMALL_MAX", 8)));
+  if (small_on && cnt <= small_max && !kinv_form_small) {
     // a handful of candidates (the caller's scalar predict_* loops): read L^-1 once instead of a padded 128-row tile GEMM
     const size_t out_bytes = sizeof(T) * 2 * PRED_SMALL_MAX + 16;
     if (!m->sm_Xs) {

@@ -1344,34 +1344,33 @@ __global__ void __launch_bounds__(256) rowdot_small_kernel(const T* __restrict__
   }
 }
 
-// one workgroup; thread q < m finishes candidate q
+// one workgroup finishes all candidates: every thread sums a strided share of the rows, fixed-order block reduction
 template <typename T>
 __global__ void __launch_bounds__(256) finish_small_kernel(const double* __restrict__ pmean, int nblk, const double* __restrict__ w, int n,
                                                            int m, const EvalParams* __restrict__ P, int want_var, T* __restrict__ mean,
                                                            T* __restrict__ var, int* __restrict__ n_warn) {
-  __shared__ double part[PRED_SMALL_MAX][17];
-  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;  // 16 slices of the rows per candidate
-  double s = 0.0;
-  if (want_var && q < m)
-    for (int i = sl; i < n; i += 16) {
-      const double v = w[(size_t)i * PRED_SMALL_MAX + q];
-      s += v * v;
-    }
-  part[q][sl] = s;
-  __syncthreads();
-  if (threadIdx.x < m) {
-    const int c = threadIdx.x;
+  __shared__ double red[4];
+  const int t = threadIdx.x;
+  for (int q = 0; q < m; ++q) {
     double mu = 0.0;
-    for (int b = 0; b < nblk; ++b) mu += pmean[(size_t)b * PRED_SMALL_MAX + c];
-    mean[c] = (T)mu;
-    if (want_var) {
-      double ss = 0.0;
-      for (int k = 0; k < 16; ++k) ss += part[c][k];
-      const T min_noise = (T)1e-5;
-      T v = (T)P->amp + min_noise - (T)ss;  // predict.rs:25-37
-      if (v < -sqrt(min_noise)) atomicAdd(n_warn, 1);
-      if (v < T(0)) v = T(0);
-      var[c] = v;
+    for (int b = t; b < nblk; b += 256) mu += pmean[(size_t)b * PRED_SMALL_MAX + q];
+    const double mu_all = block_sum(mu, red);
+    double ss = 0.0;
+    if (want_var)
+      for (int i = t; i < n; i += 256) {
+        const double v = w[(size_t)i * PRED_SMALL_MAX + q];
+        ss += v * v;
+      }
+    const double ss_all = want_var ? block_sum(ss, red) : 0.0;
+    if (t == 0) {
+      mean[q] = (T)mu_all;
+      if (want_var) {
+        const T min_noise = (T)1e-5;
+        T v = (T)P->amp + min_noise - (T)ss_all;  // predict.rs:25-37
+        if (v < -sqrt(min_noise)) atomicAdd(n_warn, 1);
+        if (v < T(0)) v = T(0);
+        var[q] = v;
+      }
     }
   }
 }
