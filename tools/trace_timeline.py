@@ -9,7 +9,8 @@ with open(sys.argv[1]) as f:
         name = r["Kernel_Name"]
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         grid = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
-        if "gemm_kernel<double, 64" in name or "gemm_kernel<double, 128" in name: cls = "gemm_big"
+        if "dag_kernel" in name: cls = "dag"
+        elif "gemm_kernel<double, 64" in name or "gemm_kernel<double, 128" in name: cls = "gemm_big"
         elif "gemm_kernel" in name: cls = "gemm32_full" if grid >= 256 else "gemm32_small"
         elif "leaf_kernel" in name: cls = "leaf"
         else: cls = "other"
@@ -19,7 +20,7 @@ rows.sort()
 lo, hi = rows[len(rows) // 10][0], rows[-len(rows) // 10][1]
 rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
 wall = hi - lo
-classes = ["gemm_big", "gemm32_full", "gemm32_small", "leaf", "other"]
+classes = ["dag", "gemm_big", "gemm32_full", "gemm32_small", "leaf", "other"]
 ev = []
 for s, e, c, q, _ in rows:
     ev.append((s, 1, c)); ev.append((e, -1, c))
