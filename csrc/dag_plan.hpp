@@ -64,7 +64,10 @@ class DagBuilder {
   // bk: contraction elements per pipeline stage (16 for f64, 32 for f32): ranges are whole stages
   // small_h: nodes whose halves are at most this many 128-blocks wide use 64x64 tiles (latency-bound products)
   // nwg: workgroups the queue is ordered for (0: keep the recursion's order)
-  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true) : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine) {}
+  // crit_rows: in the big nodes, this many block rows next to the diagonal chain (the first rows of T and of the Schur
+  //            update, the last rows of X21) also use 64x64 tiles: they sit on the critical path, where a tile's time counts
+  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true, int crit_rows = 1)
+      : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine), crit_rows_(crit_rows) {}
 
   DagPlan build(int blo, int bhi) {
     plan_ = DagPlan();
@@ -79,6 +82,7 @@ class DagBuilder {
  private:
   int bk_, small_h_, nwg_;
   bool fine_;
+  int crit_rows_ = 1;
   DagPlan plan_;
   DagCosts cost_;
 
@@ -112,6 +116,7 @@ class DagBuilder {
     int k0, k1;          // contraction block range
     int klim;            // 0 none | 1: k <= tj | 2: k >= tj | 3: k <= ti   (64-element units, as gemm_kernel's 64-tile)
     bool tri_a, tri_b;   // operand is triangular (flop accounting only)
+    int crit;            // 0 none | 1: the first crit_rows_ block rows are on the critical path | 2: the last ones
   };
   struct Tile { int kind, bi, bj, row0, col0, ka, kb; };
 
@@ -131,7 +136,8 @@ class DagBuilder {
             if (op.klim == 2) *ka = std::max(*ka, tj);
             if (op.klim == 3) *kb = std::min(*kb, ti_last + 1);
           };
-          if (small || diag) {
+          const bool crit_row = (op.crit == 1 && bi < op.r0 + crit_rows_) || (op.crit == 2 && bi >= op.r1 - crit_rows_);
+          if (small || diag || crit_row) {
             for (int hi = 0; hi < 2; ++hi) {
               const int ti = 2 * bi + hi;
               if (diag && ti < tj) continue;  // strictly upper 64-tile of a symmetric result
@@ -209,7 +215,7 @@ class DagBuilder {
     // ---- T = A21 * X11^T -> W2[2,1]
     Op t{};
     t.flags = DAGF_BBUF | DAGF_CBUF;  // A = W1, B = W2, C = W2
-    t.r0 = mid; t.r1 = hi; t.c0 = lo; t.c1 = mid; t.k0 = lo; t.k1 = mid; t.klim = 1; t.tri_b = true;
+    t.r0 = mid; t.r1 = hi; t.c0 = lo; t.c1 = mid; t.k0 = lo; t.k1 = mid; t.klim = 1; t.tri_b = true; t.crit = 1;
     const std::vector<Tile> tt = tiles_of(t, small);
     RowGates trow(hi);
     for (int i = mid; i < hi; ++i) trow[i] = DagGate{new_counter(), count_row(tt, i)};
@@ -220,7 +226,7 @@ class DagBuilder {
     // ---- A22 -= T T^T (lower) -> W1: its rows gate the right subtree
     Op s{};
     s.flags = DAGF_ABUF | DAGF_BBUF | DAGF_NEG | DAGF_ACC;  // A = B = W2, C = W1
-    s.r0 = mid; s.r1 = hi; s.c0 = mid; s.c1 = hi; s.lower = true; s.k0 = lo; s.k1 = mid;
+    s.r0 = mid; s.r1 = hi; s.c0 = mid; s.c1 = hi; s.lower = true; s.k0 = lo; s.k1 = mid; s.crit = 1;
     const std::vector<Tile> st = tiles_of(s, small);
     RowGates srow(hi);
     for (int i = mid; i < hi; ++i) srow[i] = DagGate{new_counter(), count_row(st, i)};
@@ -246,7 +252,7 @@ class DagBuilder {
     // ---- X21 = -X22 * U -> W2[2,1]
     Op x{};
     x.flags = DAGF_ABUF | DAGF_BKM | DAGF_CBUF | DAGF_NEG;  // A = W2 (X22), B = W1 (U, contraction along rows), C = W2
-    x.r0 = mid; x.r1 = hi; x.c0 = lo; x.c1 = mid; x.k0 = mid; x.k1 = hi; x.klim = 3; x.tri_a = true;
+    x.r0 = mid; x.r1 = hi; x.c0 = lo; x.c1 = mid; x.k0 = mid; x.k1 = hi; x.klim = 3; x.tri_a = true; x.crit = 2;
     const std::vector<Tile> xt = tiles_of(x, small);
     RowGates xrow(hi);
     for (int i = mid; i < hi; ++i) xrow[i] = DagGate{new_counter(), count_row(xt, i)};

@@ -425,7 +425,7 @@ struct Problem : ProblemBase {
       const int forced = env_int("HBEGP_DAG_WG", 0);
       dag_nwg = forced > 0 ? forced : std::max(1, cus / std::max(1, n_slots));
       DagBuilder builder(is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
-                         env_int("HBEGP_DAG_FINE", 1) != 0);
+                         env_int("HBEGP_DAG_FINE", 1) != 0, env_int("HBEGP_DAG_CRIT", 1));
       DagPlan plan = builder.build(0, np / NB);
       if (plan.tasks.empty()) dag_ = false;  // too many counters for 16-bit ids (n > 32k): launch-per-product path
       if (dag_ && env_int("HBEGP_DAG_VALIDATE", 0)) {
