@@ -410,10 +410,12 @@ struct Problem : ProblemBase {
     // blocks, so a problem whose slots run concurrently shares the CUs between its slots.
     // Default: on for problems whose slots run concurrently (a fit: the optimiser runs share the chip, and a resident
     // task-queue kernel keeps its CUs while another run's tile GEMMs fill the rest: measured 1.30 -> 1.56 fit+predict/s
-    // on config M); a single evaluation stream is a few per cent faster as a chain of launches (2.89 vs 3.04 ms).
+    // on config M), and for any problem of n > 4608, where the look-ahead hides the chain behind the bulk tiles (one
+    // evaluation alone, launches vs task queue: n=4096 2.92 vs 2.98 ms, 6144 7.10 vs 5.90, 8192 12.7 vs 10.6, 16384 86.3 vs
+    // 72.1); below that a single evaluation stream is a few per cent faster as a chain of launches.
     // HBEGP_DAG=0/1 forces it (read per problem: the parity tests flip it inside one process).
     const int dag_env = env_int("HBEGP_DAG", -1);
-    dag_ = (dag_env < 0 ? n_slots >= 2 : dag_env != 0) && !adhoc_ && np / NB >= 2;
+    dag_ = (dag_env < 0 ? (n_slots >= 2 || np / NB > 36) : dag_env != 0) && !adhoc_ && np / NB >= 2;
     if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
       int cus = 256;

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""One evaluation alone: task queue (256 workgroups) vs launch path, per n.  Usage: dag_vs_launch.py n [n ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hbetune_rs_amd import gpr, synth
+for n in [int(a) for a in sys.argv[1:]]:
+    w = synth.make_workload("M", n=n)
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["HBEGP_DAG"] = mode
+        prob = gpr.Problem(w["X"], w["y"])
+        ph = prob.time_eval(w["theta"], reps=3)
+        out[mode] = ph["eval_graph_ms"]
+        prob.close()
+    print(f"n={n}: launches {out['0']:.3f} ms, task queue {out['1']:.3f} ms  ({n**3 * 1e-9 / out['1']:.1f} TFLOP/s whole evaluation)", flush=True)
