@@ -353,7 +353,7 @@ struct Problem : ProblemBase {
 
   void init(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_) {
     ctx = c; n = n_; d = d_; np = round_up(n_, NB); n_slots = n_slots_;
-    nu2 = (int)std::lround(2 * nu);
+    nu2 = std::isinf(nu) ? 0 : (int)std::lround(2 * nu);  // 0 = squared exponential (nu = infinity)
     is_f32 = sizeof(T) == 4;
     // off by default: with the chunked fp64 totals of the f32 tile GEMM (kernels.hip) the plain recursion is already 2-7x
     // closer to the f64 result than LAPACK's f32 path (n=2048, cond 7e4: gradient 3e-6 vs 2e-5); refinement buys another
@@ -1405,7 +1405,7 @@ static int do_extend_from(hbegp_ctx* ctx, hbegp_model* prior, const T* X, const 
                           int* incremental) {
   if (incremental) *incremental = 0;
   const int d = prior->d, p = d + 2;
-  const double nu = prior->nu2 / 2.0;
+  const double nu = prior->nu2 == 0 ? std::numeric_limits<double>::infinity() : prior->nu2 / 2.0;
   if (prior->dev != ctx->devs[0] || n < prior->n || prior->n < NB || !prior->ldiag)
     return do_extend<T>(ctx, X, y, n, d, nu, prior->theta.data(), nullptr, nullptr, model_out);
   hbegp_ctx one;
@@ -1441,7 +1441,7 @@ static int check_args(hbegp_ctx* ctx, const void* X, const void* y, int n, int d
   if (!X || !y) return fail(HBEGP_EINVAL, "X/y is NULL");
   if (n < 1) return fail(HBEGP_EINVAL, "n must be >= 1 (got %d)", n);
   if (d < 1 || d > MAXD) return fail(HBEGP_EINVAL, "d must be in 1..%d (got %d)", MAXD, d);
-  if (!(nu == 0.5 || nu == 1.5 || nu == 2.5))
+  if (!(nu == 0.5 || nu == 1.5 || nu == 2.5 || (std::isinf(nu) && nu > 0)))  // infinity: squared exponential (extension)
     return fail(HBEGP_EINVAL, "Matern kernel with arbitrary values for nu is unimplemented (got %g)", nu);  // matern_kernel.rs:79
   return HBEGP_OK;
 }
@@ -1689,7 +1689,7 @@ int hbegp_model_info(const hbegp_model* model, int* n, int* d, int* is_f32, doub
   if (n) *n = model->n;
   if (d) *d = model->d;
   if (is_f32) *is_f32 = model->is_f32 ? 1 : 0;
-  if (nu) *nu = model->nu2 / 2.0;
+  if (nu) *nu = model->nu2 == 0 ? std::numeric_limits<double>::infinity() : model->nu2 / 2.0;
   if (lml) *lml = model->lml;
   return HBEGP_OK;
 }

@@ -769,8 +769,11 @@ template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStre
 // Kernel-matrix assembly
 // =================================================================================================================
 // Matern map of matern_kernel.rs:65-80; nu2 = 2*nu in {1,3,5}; r = euclidean distance of length-scaled points.
+// nu2 = 0 stands for nu = infinity, the squared-exponential kernel exp(-r^2/2): an extension the reference does not have
+// (matern_kernel.rs:79 is unimplemented! for other nu); its oracle is sklearn's RBF (tests/golden/*_rbf.npz).
 template <typename T>
 __device__ __forceinline__ T matern_map(T r, int nu2) {
+  if (nu2 == 0) return exp(T(-0.5) * r * r);
   if (nu2 == 1) return exp(-r);
   if (nu2 == 3) {
     const T k = r * T(1.7320508075688772);
@@ -1045,6 +1048,9 @@ __global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X,
             const T e = exp(-tt);
             km = (tt + T(1)) * e;
             gr = T(3) * e;  // matern_kernel.rs:112-118
+          } else if (nu2 == 0) {
+            km = exp(T(-0.5) * ds);  // squared exponential: dK/dlog(ell_k) = K * d_k
+            gr = km;
           } else {
             const T rr = sqrt(ds);
             km = exp(-rr);

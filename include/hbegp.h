@@ -16,7 +16,8 @@
  *   - X is n x d row-major, features in [0,1] (src/core/space.rs:141-159); y has n entries and is
  *     already y-normalised by the caller (src/core/ynormalize.rs stays in the adapter).
  *   - Kernel = ConstantKernel(c) * Matern(nu, ell_1..ell_d) + white noise s2 (src/core/gpr.rs:51, 402-427),
- *     nu in {0.5, 1.5, 2.5} (src/gpr/matern_kernel.rs:65-80).
+ *     nu in {0.5, 1.5, 2.5} (src/gpr/matern_kernel.rs:65-80).  Extension: nu = +infinity selects the squared-exponential
+ *     kernel exp(-r^2/2) (the reference has none: matern_kernel.rs:79 is unimplemented! for other nu; oracle: sklearn RBF).
  *   - theta is log-space, p = d + 2 entries ordered [ln s2, ln c, ln ell_1 .. ln ell_d]
  *     (src/gpr/fit.rs:140-144; gradient order src/gpr/lml.rs:67-68).  `lo`/`hi` are the linear-space
  *     bounds in the same order.  Kernel parameters are clamped into their bounds after exp()

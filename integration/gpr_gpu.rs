@@ -504,7 +504,8 @@ impl EstimatorGpu {
         EstimatorGpu { n_restarts_optimizer: n, ..self }
     }
 
-    /// 0.5, 1.5 or 2.5 (matern_kernel.rs:65-80; other values are `unimplemented!` there and rejected by the library)
+    /// 0.5, 1.5 or 2.5 (matern_kernel.rs:65-80; other values are `unimplemented!` there and rejected by the library);
+    /// `f64::INFINITY` selects the library's squared-exponential kernel (an extension: no CPU counterpart in hbetune)
     pub fn matern_nu(self, nu: f64) -> Self {
         EstimatorGpu { matern_nu: nu, ..self }
     }

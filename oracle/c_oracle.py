@@ -10,6 +10,13 @@ _dp = C.POINTER(C.c_double)
 _lib = None
 
 
+def _nu2(nu):
+    """2*nu as the C oracle's integer code; 0 = squared exponential (nu = infinity, an extension)."""
+    import math
+
+    return 0 if math.isinf(nu) else int(round(2 * nu))
+
+
 def load():
     global _lib
     if _lib is None:
@@ -43,7 +50,7 @@ def lml_with_gradient(x, y, noise, amplitude, length_scale, nu):
     kinv = np.zeros((n, n))
     kmat = np.zeros((n, n))
     ldiag = np.zeros(n)
-    st = lib.oracle_lml_with_gradient(_p(x), _p(y), n, d, int(round(2 * nu)), float(noise), float(amplitude), _p(ell),
+    st = lib.oracle_lml_with_gradient(_p(x), _p(y), n, d, _nu2(nu), float(noise), float(amplitude), _p(ell),
                                       _p(lml), _p(grad), _p(alpha), _p(kinv), _p(kmat), _p(ldiag))
     if st != 0:
         return None
@@ -60,6 +67,6 @@ def predict(xs, x_train, alpha, k_inv, amplitude, length_scale, nu, want_varianc
     m, d = xs.shape
     mean = np.zeros(m)
     var = np.zeros(m) if want_variance else None
-    warn = lib.oracle_predict(_p(xs), m, _p(x_train), x_train.shape[0], d, int(round(2 * nu)), float(amplitude), _p(ell),
+    warn = lib.oracle_predict(_p(xs), m, _p(x_train), x_train.shape[0], d, _nu2(nu), float(amplitude), _p(ell),
                               _p(alpha), _p(k_inv), _p(mean), _p(var))
     return mean, var, warn

@@ -26,6 +26,7 @@ static double matern_from_scaled(const double* xa, const double* xb, int d, int 
     accum += df * df; /* powi(2) */
   }
   double dist = sqrt(accum);
+  if (nu2 == 0) return exp(-0.5 * accum); /* squared exponential (nu = infinity): extension, not in the reference */
   if (nu2 == 1) return exp(-dist);
   if (nu2 == 3) {
     double k = dist * sqrt(3.0);
@@ -132,6 +133,8 @@ int oracle_lml_with_gradient(const double* x, const double* y, int n, int d, int
           if (!isfinite(gm)) gm = 0.0;
         } else if (nu2 == 3) { /* :112-118 */
           gm = g[1 + k] * exp(-sqrt(dsum * 3.0)) * 3.0;
+        } else if (nu2 == 0) { /* squared exponential: dK/dlog(ell_k) = K d_k */
+          gm = km * g[1 + k];
         } else { /* :119-131 */
           double tmp = sqrt(dsum * 5.0);
           gm = exp(-tmp) * (tmp + 1.0) * g[1 + k] * (5.0 / 3.0);

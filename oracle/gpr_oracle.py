@@ -71,6 +71,10 @@ def matern_kernel(x1, x2, length_scale, nu):
     if nu == 2.5:
         k = dists * A(math.sqrt(5.0))  # :73
         return (A(1) + k + k * k / A(3)) * np.exp(-k)  # :75
+    if math.isinf(nu):
+        # squared exponential (the nu -> inf limit).  NOT in the reference (:79 is unimplemented! for other nu): an extension
+        # the north star names; its only oracle is sklearn's RBF (tests/golden/*_rbf.npz)
+        return np.exp(-A(0.5) * dists * dists)
     raise NotImplementedError("Matern kernel with arbitrary values for nu")  # :79
 
 
@@ -95,6 +99,8 @@ def matern_theta_grad(x, length_scale, nu):
     elif nu == 2.5:
         tmp = np.sqrt(dsum * A(5))[:, :, None]  # :120-122
         grad = np.exp(-tmp) * (tmp + A(1)) * d * A(5.0 / 3.0)  # :123-130
+    elif math.isinf(nu):
+        grad = np.exp(-A(0.5) * dsum)[:, :, None] * d  # dK/dlog(ell_k) = K * d_k  (extension, see matern_kernel)
     else:
         raise NotImplementedError("Matern kernel gradient with arbitrary values for nu")
     return kernel, grad

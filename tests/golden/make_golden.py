@@ -19,7 +19,7 @@ import sys
 import numpy as np
 from scipy.linalg import solve_triangular
 from sklearn.gaussian_process import GaussianProcessRegressor
-from sklearn.gaussian_process.kernels import ConstantKernel, Matern, WhiteKernel
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, WhiteKernel
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
@@ -36,6 +36,9 @@ CASES = [
     ("c5_himmelblau_n128", "C5", 128, 2.5, 32),
     ("m_rosenbrock_n256", "M", 256, 2.5, 64),
     ("m_rosenbrock_n100_ragged", "M", 100, 2.5, 7),
+    # squared-exponential kernel (nu = inf): no reference behaviour to match (matern_kernel.rs:79 is unimplemented!), sklearn's RBF is the oracle
+    ("c2_rosenbrock_n192_rbf", "C2", 192, float("inf"), 48),
+    ("c1_sphere_n64_rbf", "C1", 64, float("inf"), 32),
 ]
 
 
@@ -45,7 +48,8 @@ def sk_case(name, cfg, n, nu, m):
     d = w["d"]
     s2, c = math.exp(theta[0]), math.exp(theta[1])
     ell = np.exp(theta[2:])
-    kernel = ConstantKernel(c) * Matern(length_scale=ell, nu=nu) + WhiteKernel(s2)
+    base = RBF(length_scale=ell) if math.isinf(nu) else Matern(length_scale=ell, nu=nu)
+    kernel = ConstantKernel(c) * base + WhiteKernel(s2)
     gp = GaussianProcessRegressor(kernel=kernel, alpha=0.0, optimizer=None, normalize_y=False).fit(X, y)
     sk_theta = gp.kernel_.theta  # [ln c, ln ell..., ln s2]
     lml, g = gp.log_marginal_likelihood(sk_theta, eval_gradient=True)
@@ -124,6 +128,10 @@ REFERENCE_KATS = {
         "x": [-2.0, -2.0], "f": -4.0,
     },
 }
+
+# Vectors held by the reference's ynormalize.rs / acquisition.rs unit tests (data only; see tests/test_estimator_cpu.py)
+REFERENCE_KATS["ynormalize"] = {'source': 'src/core/ynormalize.rs unit tests (data only): logwarp :48-75, :125-147; tests :324-521', 'logwarp_project_mean_from': {'source': 'ynormalize.rs:48-75', 'logmean': [-1.0, 0.0, 0.5, 1.0, 0.0, 0.0], 'logstd': [1.0, 1.0, 1.0, 1.0, 0.5, 2.0], 'expected_exponents': [-0.5, 0.5, 1.0, 1.5, 0.125, 2.0], 'epsilon': 1e-06}, 'logwarp_project_variance': {'source': 'ynormalize.rs:125-147 (sqrt(variance) == mean * sqrt(exp(s^2) - 1))', 'logmean': [-1.0, 0.0, 0.5, 1.0, 0.0, 0.0], 'logstd': [1.0, 1.0, 1.0, 1.0, 0.5, 2.0], 'epsilon': 1e-07}, 'lognormal_from_data': {'source': 'ynormalize.rs:78-112', 'mu': -1.0, 'sigma': 1.0, 'count': 500, 'mean_max_relative': 0.05, 'std_max_relative': 0.15, 'note': 'the reference draws from its own RNG (seed 83229, random.rs); the stream is not reproducible here, the distribution and tolerances are'}, 'inverse': {'source': 'ynormalize.rs:324-383', 'epsilon': 0.0001, 'cases': [{'input': [1.0, 2.0, 3.0, 4.0], 'projection': 'linear', 'known_optimum': None}, {'input': [1.0, 2.0, 3.0, 4.0], 'projection': 'linear', 'known_optimum': 0.0}, {'input': [1.0, 2.0, 3.0, 4.0], 'projection': 'logarithmic', 'known_optimum': None}, {'input': [1.0, 2.0, 3.0, 4.0], 'projection': 'logarithmic', 'known_optimum': 0.0}, {'input': [-5.0, 3.0, 8.0, -2.0], 'projection': 'linear', 'known_optimum': None}, {'input': [-5.0, 3.0, 8.0, -2.0], 'projection': 'linear', 'known_optimum': 0.0}]}, 'linear_variance': {'source': 'ynormalize.rs:385-399', 'expected': 1234.0, 'amplitude': 3.0, 'variance': [0.0, 1.0, 4.0], 'std': [0.0, 3.0, 6.0], 'epsilon': 0.0001}, 'logarithmic_mean': {'source': 'ynormalize.rs:401-463', 'epsilon': 1e-07, 'cases': [{'expected': 0.0, 'amplitude': 1.0, 'mean': 0.5, 'std': 1.0, 'want': 2.718281828459045}, {'expected': 0.0, 'amplitude': 1.0, 'mean': 2.0, 'std': 3.0, 'want': 665.1416330443618}, {'expected': 0.0, 'amplitude': 2.0, 'mean': 0.5, 'std': 1.0, 'want': 20.085536923187664}, {'expected': 0.0, 'amplitude': 2.0, 'mean': 1.0, 'std': 1.5, 'want': 665.1416330443618}, {'expected': 1.0, 'amplitude': 1.0, 'mean': 0.5, 'std': 1.0, 'want': 3.718281828459045}]}, 'statistics': {'source': 'ynormalize.rs:465-521', 'mu': 3.0, 'sigma': 1.0, 'count': 500, 'linear': {'mean_ratio': 1e-07, 'std_ratio': 1e-07}, 'logarithmic': {'mean_ratio': 0.01, 'std_ratio': 0.1}, 'note': "data = exp(normal(3, 1)) x 500 from the reference's RNG (seed 903282318); stream not reproducible here"}}
+REFERENCE_KATS["expected_improvement"] = {'source': 'src/core/acquisition.rs:141-171 (contract: std <= 0 or |std| <= f64::EPSILON -> max(fmin - mean, 0); else -(mean-fmin) Phi(z) + std phi(z), z = -(mean-fmin)/std; finite and >= 0)'}
 
 if __name__ == "__main__":
     for case in CASES:

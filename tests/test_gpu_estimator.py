@@ -315,3 +315,28 @@ def test_confidence_bound_suggestion_and_fitness_sort_match_the_oracle(oracle_pi
     keep = E.FitnessOperator(model, "prediction").select_next_population(feats[:30], feats[30:])
     gap = np.abs(want_fit[:30] - want_fit[30:]) > 1e-9
     assert np.array_equal(keep[gap], ~(want_fit[:30] < want_fit[30:])[gap])
+
+
+def test_squared_exponential_kernel_through_the_estimator():
+    # nu = inf selects exp(-r^2/2) (an extension: the reference has Matern only, matern_kernel.rs:79); prior reuse keeps it
+    from oracle import gpr_oracle as O
+
+    rng = np.random.default_rng(12)
+    X = rng.random((90, 2))
+    y = np.sin(4 * X[:, 0]) * np.cos(3 * X[:, 1])
+    est = EstimatorGPR.new(2).matern_nu(float("inf")).noise_bounds(1e-4, 1e0)
+    model = est.estimate(X, y, None, RNG.new_with_seed(3))
+    fk = model.fitted
+    assert np.isinf(fk.nu)
+    yn = model.y_norm.project_into_normalized(y)
+    ref = O.extend(X, yn, fk.noise, fk.amplitude, fk.length_scale, float("inf"))
+    assert abs(fk.lml - ref["lml"]) <= 1e-8 * max(1.0, abs(ref["lml"]))
+    Xs = rng.random((30, 2))
+    m, v, _ = O.predict(Xs, X, ref["alpha"], ref["k_inv"], fk.amplitude, fk.length_scale, float("inf"))
+    md, vd = model._predict_norm(Xs)
+    np.testing.assert_allclose(md, m, rtol=0, atol=1e-7 * max(1.0, np.abs(m).max()))
+    np.testing.assert_allclose(vd, np.maximum(v, 0), rtol=0, atol=1e-7 * fk.amplitude)
+    truth = np.sin(4 * Xs[:, 0]) * np.cos(3 * Xs[:, 1])
+    assert np.sqrt(np.mean((model.predict_mean_a(Xs) - truth) ** 2)) < 0.05
+    again = EstimatorGPR.new(2).estimate(X, y, model, RNG.new_with_seed(4))  # the prior hands over its kernel, nu included
+    assert np.isinf(again.fitted.nu)

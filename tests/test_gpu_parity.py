@@ -123,7 +123,7 @@ def test_ill_conditioned_kernel_matrix_stays_inside_the_bar(noise_rel, ell_scale
     np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=F64_TOL * np.abs(ref["k_inv"]).max())
 
 
-@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5])
+@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5, float("inf")])  # inf = squared exponential (extension; oracle pinned on sklearn RBF goldens)
 def test_all_matern_orders(nu):
     w = synth.make_workload("C1")
     s2, c, ell = split_theta(w["theta"])
