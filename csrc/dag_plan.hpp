@@ -36,6 +36,23 @@
 
 namespace hbegp {
 
+// Where a node [lo, hi) of the recursion is split.  Default: in the middle, as the launch path does (same arithmetic, same
+// bits).  HBEGP_SPLIT_NUM/HBEGP_SPLIT_DEN (experiment, task queue only): nodes wider than HBEGP_SPLIT_MIN blocks put num/den
+// of their blocks into the LEFT part -- a smaller left part shortens the chain-bound head of the factorisation (nothing but
+// the diagonal chain can run until the left part is done) at the price of a longer chain later.  Simulated for n=4096, 85
+// workgroups: 1/2 -> 2932 us, 3/8 -> 2932, 1/3 -> 2887, 1/4 -> 3015, 1/8 -> 3045: nothing to gain, the default stays.
+inline int dag_split_point(int lo, int hi) {
+  static const int num = getenv("HBEGP_SPLIT_NUM") ? atoi(getenv("HBEGP_SPLIT_NUM")) : 1;
+  static const int den = getenv("HBEGP_SPLIT_DEN") ? atoi(getenv("HBEGP_SPLIT_DEN")) : 2;
+  static const int minw = getenv("HBEGP_SPLIT_MIN") ? atoi(getenv("HBEGP_SPLIT_MIN")) : 8;
+  const int w = hi - lo;
+  if (w <= minw || den <= 0 || num <= 0 || num >= den) return lo + w / 2;
+  int left = (w * num) / den;
+  // keep the parts multiples of 4 blocks where possible (small nodes stay balanced binary trees)
+  left = std::max(4, left / 4 * 4);
+  return lo + std::min(left, w - 1);
+}
+
 struct DagPlan {
   std::vector<DagTask> tasks;
   std::vector<int> totals;  // per counter: number of tasks that bump it
@@ -208,7 +225,7 @@ class DagBuilder {
       out.all = DagGate{c, 1};
       return out;
     }
-    const int mid = lo + (hi - lo) / 2;
+    const int mid = dag_split_point(lo, hi);
     const bool small = std::max(mid - lo, hi - mid) <= small_h_;
     const Sub left = rec(lo, mid, gate);
     double cu = 0;
