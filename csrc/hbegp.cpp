@@ -426,9 +426,26 @@ struct Problem : ProblemBase {
       }
       const int forced = env_int("HBEGP_DAG_WG", 0);
       dag_nwg = forced > 0 ? forced : std::max(1, cus / std::max(1, n_slots));
-      DagBuilder builder(is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
-                         env_int("HBEGP_DAG_FINE", 1) != 0, env_int("HBEGP_DAG_CRIT", 1));
-      DagPlan plan = builder.build(0, np / NB);
+      // plans depend only on (blocks, stage depth, tiling and ordering knobs): the caller fits one model per generation with
+      // slowly growing n, so they are kept (building + simulating the n=4096 queue costs ~15 ms of host time per fit)
+      const std::array<int, 7> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
+                                      env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), 0};
+      static std::mutex cache_mu;
+      static std::map<std::array<int, 7>, std::shared_ptr<const DagPlan>> cache;
+      std::shared_ptr<const DagPlan> cached;
+      {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) cached = it->second;
+      }
+      if (!cached) {
+        DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5]);
+        cached = std::make_shared<const DagPlan>(builder.build(0, np / NB));
+        std::lock_guard<std::mutex> lk(cache_mu);
+        if (cache.size() > 64) cache.clear();
+        cache[key] = cached;
+      }
+      const DagPlan& plan = *cached;
       if (plan.tasks.empty()) dag_ = false;  // too many counters for 16-bit ids (n > 32k): launch-per-product path
       if (dag_ && env_int("HBEGP_DAG_VALIDATE", 0)) {
         const std::string why = dag_plan_validate(plan, np / NB);
@@ -1238,7 +1255,10 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   for (int r = 0; r < nruns; ++r) runs_on[r % ndev]++;
   int n_slots = 1;
   for (int di = 0; di < ndev; ++di) n_slots = std::max(n_slots, std::min(runs_on[di], max_conc));
+  static const int timing = env_int("HBEGP_TIMING", 0);
+  const auto tf0 = std::chrono::steady_clock::now();
   Problem<T> prob(ctx, X, y, n, d, nu, n_slots);
+  const auto tf1 = std::chrono::steady_clock::now();
 
   std::vector<double> lnlo(p), lnhi(p);
   for (int i = 0; i < p; ++i) {
@@ -1368,7 +1388,13 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   }
   if (theta_best) memcpy(theta_best, th.data(), sizeof(double) * p);
   if (lml_best) *lml_best = best.best_lml;
+  const auto tf2 = std::chrono::steady_clock::now();
   if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml);
+  if (timing) {
+    const auto tf3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "fit: problem %.2f ms, optimiser runs %.2f ms (%d evaluations), model %.2f ms\n", ms(tf0, tf1), ms(tf1, tf2), n_evals.load(), ms(tf2, tf3));
+  }
   return HBEGP_OK;
 }
 

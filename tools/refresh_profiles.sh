@@ -40,3 +40,9 @@ python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cut -c1-300 "$OUT/${TAG}_bench.json"
 cat "$OUT/pmc_sq_summary.log"
 ls -la "$OUT"
+echo "[extra] kernel trace of one f32 evaluation (C5: himmelblau n=2048, --use-32)"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5" -o run -- python3 "$ROOT/tools/profile_eval.py" C5 > "$OUT/eval_c5.log" 2>&1
+cp "$OUT/c5/run_kernel_stats.csv" "$OUT/${TAG}_c5_f32_kernel_stats.csv"
+rm -rf "$OUT/c5"
+cd "$ROOT"
