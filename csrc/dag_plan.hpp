@@ -46,7 +46,7 @@ inline int dag_split_point(int lo, int hi) {
   static const int den = getenv("HBEGP_SPLIT_DEN") ? atoi(getenv("HBEGP_SPLIT_DEN")) : 2;
   static const int minw = getenv("HBEGP_SPLIT_MIN") ? atoi(getenv("HBEGP_SPLIT_MIN")) : 8;
   const int w = hi - lo;
-  if (w <= minw || den <= 0 || num <= 0 || num >= den) return lo + w / 2;
+  if (w <= minw || den <= 0 || num <= 0 || num >= den || 2 * num == den) return lo + w / 2;  // default: exactly the launch path's split
   int left = (w * num) / den;
   // keep the parts multiples of 4 blocks where possible (small nodes stay balanced binary trees)
   left = std::max(4, left / 4 * 4);

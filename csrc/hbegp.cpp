@@ -1596,7 +1596,28 @@ static int problem_get(hbegp_problem* prob, int dev, int slot, T* alpha, T* kinv
   return HBEGP_OK;
   GUARD_END
 }
+template <typename T>
+static int problem_debug_get(hbegp_problem* prob, int dev, int slot, int which, T* out) {
+  if (!prob || !out) return fail(HBEGP_EINVAL, "NULL argument");
+  auto* p = dynamic_cast<Problem<T>*>(prob->impl.get());
+  if (!p) return fail(HBEGP_EINVAL, "element type mismatch");
+  if (dev < 0 || dev >= (int)p->slots.size() || slot < 0 || slot >= p->n_slots || (which != 1 && which != 2))
+    return fail(HBEGP_EINVAL, "bad device/slot/which");
+  GUARD_BEGIN
+  Slot<T>& s = p->slots[dev][slot];
+  HIPCHECK(hipSetDevice(s.dev));
+  HIPCHECK(hipStreamSynchronize(s.stream));
+  HIPCHECK(hipMemcpy(out, which == 1 ? s.W1 : s.W2, sizeof(T) * (size_t)p->np * p->np, hipMemcpyDeviceToHost));
+  return HBEGP_OK;
+  GUARD_END
+}
 extern "C" {
+int hbegp_problem_debug_get_f64(hbegp_problem* prob, int dev, int slot, int which, double* out) {
+  return problem_debug_get<double>(prob, dev, slot, which, out);
+}
+int hbegp_problem_debug_get_f32(hbegp_problem* prob, int dev, int slot, int which, float* out) {
+  return problem_debug_get<float>(prob, dev, slot, which, out);
+}
 int hbegp_problem_get_f64(hbegp_problem* prob, int dev, int slot, double* alpha, double* kinv, double* ldiag) {
   return problem_get<double>(prob, dev, slot, alpha, kinv, ldiag);
 }

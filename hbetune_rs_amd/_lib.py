@@ -57,6 +57,8 @@ SIGNATURES = {
     "hbegp_problem_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "hbegp_problem_get_f64": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "hbegp_problem_get_f32": (C.c_int, [_vp, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "hbegp_problem_debug_get_f64": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "hbegp_problem_debug_get_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _fp]),
     "hbegp_problem_kmat_f64": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
     "hbegp_problem_kmat_f32": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _fp]),
     "hbegp_problem_time_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp]),

@@ -114,6 +114,14 @@ class Problem:
         _lib.check(get(self._h, dev, slot, _lib.aptr(alpha), _lib.aptr(kinv), _lib.aptr(ldiag)))
         return alpha, kinv, ldiag
 
+    def debug_work_matrix(self, which, dev=0, slot=0):
+        """Raw copy of W1 (which=1) or W2 (which=2) after the last evaluation: [np, np] with np = n rounded up to 128."""
+        npad = (self.n + 127) // 128 * 128
+        out = np.zeros((npad, npad), dtype=self.dtype)
+        get = getattr(_lib.load(), f"hbegp_problem_debug_get_{self._sfx}")
+        _lib.check(get(self._h, dev, slot, which, _lib.aptr(out)))
+        return out
+
     def kernel_matrix(self, theta, lo=None, hi=None, dev=0, slot=0):
         lib = _lib.load()
         theta = _lib.as_c(theta, np.float64)

@@ -173,6 +173,11 @@ typedef double (*hbegp_objective_fn)(const double* x, double* grad, void* user);
 double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, const double* lo, const double* hi,
                                   int n, int maxeval);
 
+/* ---- test hook: raw copy of a slot's work matrix after the last evaluation (np x np row-major, np = n rounded up to 128;
+ * which = 1: W1 (Schur complements / U), 2: W2 (X = L^-1).  out holds np*np elements of the problem's type. */
+int hbegp_problem_debug_get_f64(hbegp_problem* prob, int dev, int slot, int which, double* out);
+int hbegp_problem_debug_get_f32(hbegp_problem* prob, int dev, int slot, int which, float* out);
+
 /* ---- test hook (host only, no GPU): build the task queue of the device-scheduled factorisation for `nblocks`
  * 128-blocks (bk = contraction elements per stage: 16 for f64, 32 for f32; nodes up to small_h blocks wide use 64x64
  * tiles; nwg > 0: order the queue by a list schedule simulated for nwg workgroups; fine: per-row-block dependencies) and

@@ -26,6 +26,7 @@ def _eval_all(X, y, theta, monkeypatch, dag, n_slots=1, reps=2, **env):
 
 
 @pytest.mark.parametrize("n,cfg,dtype", [(200, "C2", np.float64), (256, "C1", np.float64), (300, "M", np.float64), (1100, "C3", np.float64),
+                                          (1300, "M", np.float64), (1409, "C2", np.float64), (1900, "M", np.float64),  # 11, 12, 15 blocks: odd splits
                                           (2048, "M", np.float64), (600, "C5", np.float32), (1536, "C5", np.float32)])
 def test_task_queue_is_bitwise_equal_to_launch_path(n, cfg, dtype, monkeypatch):
     w = synth.make_workload(cfg, n=n)
@@ -92,3 +93,34 @@ def test_concurrent_slots_share_the_chip_and_agree(monkeypatch):
         for rep in range(6):
             k = (rep + slot) % 3
             assert res[slot][rep][0] == single[k][0] and np.array_equal(res[slot][rep][1], single[k][1])
+
+
+def test_concurrent_soak_against_launch_path(monkeypatch):
+    # tools/dag_soak.py in small: 3 slots x 40 rounds of different theta at once (odd block count), every result bit for bit
+    # what the launch path returns on a quiet device -- a stale operand anywhere would show
+    import threading
+
+    monkeypatch.delenv("HBEGP_DAG", raising=False)
+    w = synth.make_workload("M", n=1300)
+    X, y = w["X"], w["y"]
+    rng = np.random.default_rng(7)
+    rounds = 40
+    thetas = w["theta"][None, :] + 0.15 * rng.standard_normal((3 * rounds, len(w["theta"])))
+    prob = gpr.Problem(X, y, n_slots=3)
+    got = [None] * len(thetas)
+
+    def work(slot):
+        for r in range(rounds):
+            got[3 * r + slot] = prob.lml_with_gradient(thetas[3 * r + slot], slot=slot)
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    prob.close()
+    monkeypatch.setenv("HBEGP_DAG", "0")
+    ref = gpr.Problem(X, y)
+    for i, th in enumerate(thetas):
+        r = ref.lml_with_gradient(th)
+        assert (r is None) == (got[i] is None)
+        if r is not None:
+            assert r[0] == got[i][0] and np.array_equal(r[1], got[i][1]), i
