@@ -204,6 +204,167 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
       }
 }
 
+// ---- the launches around the factorisation as tasks: SAME arithmetic per element as kmat_kernel, trmv_n_kernel,
+// trmv_t_kernel, alpha_reduce_kernel and lml_final_kernel (kernels.hip), only the thread -> element mapping is carried
+// over to 512-thread workgroups (two 256-thread halves).  Anything another workgroup of this launch reads is stored
+// write-through.
+template <typename T>
+__device__ __forceinline__ void dag_kmat_tile(const DagLaunch& g, int row0, int col0, T* __restrict__ W, char* smem_raw) {
+  const int d = g.d, n = g.n, np = g.ld, nu2 = g.nu2;
+  const T* X = static_cast<const T*>(g.X);
+  const EvalParams* P = g.P;
+  T* xj = reinterpret_cast<T*>(smem_raw);   // [d][64] scaled rows of the j tile
+  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+  T* xi = xj + (size_t)d * 64 * (1 + half);  // [d][64] per half
+  const int i0 = row0 + 64 * half, j0 = col0;
+  const bool active = i0 >= j0;  // a 64x64 tile strictly above the diagonal is never stored (kmat_kernel launches lower tiles only)
+  for (int e = t; e < 64 * d; e += 256) {
+    const int row = e / d, k = e - row * d;
+    const T ell = (T)P->ell[k];
+    const int gi = i0 + row, gj = j0 + row;
+    xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] / ell : T(0);
+    if (half == 0) xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
+  }
+  __syncthreads();
+  if (!active) return;
+  const int tx = t & 15, ty = t >> 4;
+  T acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
+  for (int k = 0; k < d; ++k) {
+    T a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T df = a[r] - b[c];
+        acc[r][c] += df * df;
+      }
+  }
+  const T amp = (T)P->amp, noise = (T)P->noise;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int gi = i0 + ty + 16 * r;
+    T* p = W + (size_t)gi * np + j0 + tx * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gj = j0 + tx * 4 + c;
+      T v;
+      if (gi < n && gj < n) {
+        v = amp * matern_map<T>(sqrt(acc[r][c]), nu2);
+        if (gi == gj) v += noise;
+      } else {
+        v = (gi == gj) ? T(1) : T(0);
+      }
+      gstore<true>(p + c, v);
+    }
+  }
+}
+
+// 256-thread block sum inside a 512-thread workgroup: threads >= 256 contribute nothing but join the barriers
+__device__ __forceinline__ double dag_block_sum256(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0 && wave < 4) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__device__ __forceinline__ void dag_trmv_n(const DagLaunch& g, int row0, const T* __restrict__ Xinv) {
+  // trmv_n_kernel: one wave per row, 4 rows per wave here (32 rows per task)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* y = static_cast<const T*>(g.y);
+  T* w = static_cast<T*>(g.wbuf);
+  for (int q = 0; q < 4; ++q) {
+    const int row = row0 + wave * 4 + q;
+    if (row >= g.ld) continue;
+    double acc = 0;
+    const T* xr = Xinv + (size_t)row * g.ld;
+    for (int k = lane; k <= row && k < g.n; k += 64) acc = __builtin_fma((double)xr[k], (double)y[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) gstore<true>(&w[row], (T)acc);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void dag_trmv_t(const DagLaunch& g, int chunk, int col0, const T* __restrict__ Xinv, char* smem_raw) {
+  // trmv_t_kernel: 64 columns x 4 row groups per 256 threads; two such column groups per task
+  double* red = reinterpret_cast<double*>(smem_raw);  // [2][4][64]
+  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+  const int c = t & 63, sgrp = t >> 6;
+  const int np = g.ld;
+  const int cg0 = col0 + 64 * half, j = cg0 + c;
+  const T* w = static_cast<const T*>(g.wbuf);
+  double acc = 0;
+  const int i_begin = chunk * 256, i_end = min(i_begin + 256, np);
+  if (i_end > cg0) {
+    for (int i = i_begin + sgrp; i < i_end; i += 4)
+      if (i >= j) acc = __builtin_fma((double)Xinv[(size_t)i * np + j], (double)w[i], acc);
+  }
+  red[(half * 4 + sgrp) * 64 + c] = acc;
+  __syncthreads();
+  if (sgrp == 0 && i_end > cg0) {
+    const double* r = red + half * 256;
+    gstore<true>(&g.part_t[(size_t)chunk * np + j], r[c] + r[64 + c] + r[128 + c] + r[192 + c]);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void dag_alpha_reduce(const DagLaunch& g, int blk, char* smem_raw) {
+  // alpha_reduce_kernel, block `blk` of 256 columns (threads 0..255)
+  double* red = reinterpret_cast<double*>(smem_raw);
+  const int np = g.ld, n = g.n;
+  const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
+  const int j = blk * 256 + (int)threadIdx.x;
+  const T* y = static_cast<const T*>(g.y);
+  const T* ldiag = static_cast<const T*>(g.ldiag);
+  T* alpha = static_cast<T*>(g.alpha);
+  double ya = 0, ld = 0;
+  if (threadIdx.x < 256 && j < np) {
+    double a = 0;
+    for (int c = j / 256; c < nchunks; ++c) a += g.part_t[(size_t)c * np + j];
+    const T at = (T)a;
+    alpha[j] = (j < n) ? at : T(0);
+    if (j < n) {
+      ya = (double)y[j] * (double)at;
+      ld = log((double)ldiag[j]);
+    }
+  }
+  const double s1 = dag_block_sum256(ya, red);
+  const double s2 = dag_block_sum256(ld, red);
+  if (threadIdx.x == 0) {
+    double* sums = g.part_t + (size_t)nchunks * np;
+    gstore<true>(&sums[2 * blk], s1);
+    gstore<true>(&sums[2 * blk + 1], s2);
+  }
+}
+
+__device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
+  if (threadIdx.x == 0) {
+    const int np = g.ld;
+    const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
+    const int nblocks = (np + 255) / 256;
+    const double* sums = g.part_t + (size_t)nchunks * np;
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      s1 += sums[2 * b];
+      s2 += sums[2 * b + 1];
+    }
+    g.out->yalpha = s1;
+    g.out->logdet = s2;
+    g.out->lml = __builtin_fma(-0.5, s1, -s2) - (double)g.n / 2.0 * log(2.0 * 3.14159265358979323846);
+    atomicOr(&g.out->done, 1);
+  }
+}
+
 // bounded wait for one counter; false: give up (another workgroup timed out, or this one did)
 __device__ __forceinline__ bool dag_wait(int* ctrl, int* info, int cnt, int val, int task_idx) {
   int* c = ctrl + DAG_CTRL_WORDS + cnt;
@@ -277,8 +438,18 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
         leaf_body<double, T, true>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, 0, smem_raw);
       } else if (kind == DAG_GEMM_128x64) {
         dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
-      } else {
+      } else if (kind == DAG_GEMM_64x64) {
         dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
+      } else if (kind == DAG_KMAT) {
+        dag_kmat_tile<T>(g, row0, col0, W1, smem_raw);
+      } else if (kind == DAG_TRMV_N) {
+        dag_trmv_n<T>(g, row0, W2);
+      } else if (kind == DAG_TRMV_T) {
+        dag_trmv_t<T>(g, row0, col0, W2, smem_raw);
+      } else if (kind == DAG_ALPHA_REDUCE) {
+        dag_alpha_reduce<T>(g, col0, smem_raw);
+      } else if (kind == DAG_LML_FINAL) {
+        dag_lml_final(g);
       }
     }
     const int cur_idx = __builtin_amdgcn_readfirstlane(ctl[0]);

@@ -74,6 +74,7 @@ struct DagCosts {
   double overhead = 1.5 + 4.0;
   double per128_big = 7.9;
   double per128_small = 3.9;
+  double kmat = 9.0;  // one 128x64 kernel-matrix tile (fp64 exp/sqrt bound: 36 us for the 1056 tiles of n=4096 on 256 CUs)
 };
 
 class DagBuilder {
@@ -86,9 +87,15 @@ class DagBuilder {
   DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true, int crit_rows = 1)
       : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine), crit_rows_(crit_rows) {}
 
-  DagPlan build(int blo, int bhi) {
+  // full = true: the kernel-matrix tiles in front of the recursion and the alpha / lml reductions behind it are tasks of the
+  // same queue (whole matrix only: blo = 0, bhi = np / 128)
+  DagPlan build(int blo, int bhi, bool full = false) {
     plan_ = DagPlan();
-    rec(blo, bhi, nullptr);
+    if (full && blo == 0) {
+      build_full(bhi);
+    } else {
+      rec(blo, bhi, nullptr);
+    }
     if (plan_.totals.size() >= 0xffff) plan_.tasks.clear();  // counter ids are 16-bit: the caller falls back
     for (int tot : plan_.totals)
       if (tot > 0xffff) plan_.tasks.clear();
@@ -285,6 +292,62 @@ class DagBuilder {
     return out;
   }
 
+  // kmat tiles -> recursion (gated row by row by the tiles of its block row) -> w = X y -> partials of X^T w -> alpha,
+  // y^T alpha, log det -> lml.  Task shapes and reduction orders are those of kmat_kernel / trmv_n_kernel / trmv_t_kernel /
+  // alpha_reduce_kernel / lml_final_kernel, so the results are the launch path's, bit for bit.
+  void build_full(int nb) {
+    const int np = nb * 128;
+    RowGates krow(nb);
+    for (int bi = 0; bi < nb; ++bi) krow[bi] = DagGate{new_counter(), 2 * (bi + 1)};
+    for (int bi = 0; bi < nb; ++bi)
+      for (int tj = 0; tj <= 2 * bi + 1; ++tj) {
+        DagTask t{};
+        t.kind = DAG_KMAT;
+        t.row0 = bi * 128; t.col0 = tj * 64;
+        push(t, {}, krow[bi].cnt, -1, cost_.kmat);
+      }
+    const Sub root = rec(0, nb, &krow);
+    // w = X y, 32 rows per task
+    const int nchunks = (np + 255) / 256;
+    RowGates wchunk(nchunks);
+    for (int c = 0; c < nchunks; ++c) wchunk[c] = DagGate{new_counter(), (std::min(np, 256 * (c + 1)) - 256 * c) / 32};
+    for (int g = 0; g < np / 32; ++g) {
+      DagTask t{};
+      t.kind = DAG_TRMV_N;
+      t.row0 = 32 * g;
+      push(t, {root.rowfin[(32 * g) / 128]}, wchunk[(32 * g) / 256].cnt, -1, cost_.overhead + 0.02 * (32 * g / 128 + 1) * 32 / 8);
+    }
+    // partials of X^T w: chunk c of 256 rows x 128 columns
+    const int nblocks = (np + 255) / 256;
+    RowGates pcol(nblocks);
+    for (int b = 0; b < nblocks; ++b) pcol[b] = DagGate{new_counter(), 0};
+    struct TT { int c, q; };
+    std::vector<TT> tts;
+    for (int c = 0; c < nchunks; ++c) {
+      const int i_end = std::min(256 * (c + 1), np);
+      for (int q = 0; q * 128 < i_end; ++q) {
+        tts.push_back({c, q});
+        pcol[(128 * q) / 256].val++;
+      }
+    }
+    for (const TT& tt : tts) {
+      DagTask t{};
+      t.kind = DAG_TRMV_T;
+      t.row0 = tt.c; t.col0 = 128 * tt.q;
+      push(t, {wchunk[tt.c]}, pcol[(128 * tt.q) / 256].cnt, -1, cost_.overhead + 4.0);
+    }
+    const DagGate rall{new_counter(), nblocks};
+    for (int b = 0; b < nblocks; ++b) {
+      DagTask t{};
+      t.kind = DAG_ALPHA_REDUCE;
+      t.col0 = b;
+      push(t, {pcol[b]}, rall.cnt, -1, cost_.overhead + 2.0);
+    }
+    DagTask f{};
+    f.kind = DAG_LML_FINAL;
+    push(f, {rall}, -1, -1, cost_.overhead);
+  }
+
   // Reorder the queue: simulate a list schedule with nwg_ workers, priority = longest remaining path.
   void order() {
     const int nt = (int)plan_.tasks.size(), nc = (int)plan_.totals.size();
@@ -380,11 +443,13 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
   // known[task] = set of counters whose full count happened before the task STARTS; done_known[c] = union over the
   // tasks bumping c of (known[task] + nothing): what a waiter on c learns
   std::vector<uint64_t> counter_known((size_t)nc * words, 0), cur(words);
-  const int nt64 = nblocks_total * 2;
+  const int nt64 = nblocks_total * 4;  // table dimension: 64x64 tiles need 2 per block, the 32-row cells of w need 4
   struct Cell { int writer = -1; std::vector<int> readers; };
-  std::vector<Cell> cells[2];
-  cells[0].resize((size_t)nt64 * nt64);
-  cells[1].resize((size_t)nt64 * nt64);
+  // buffers 0/1: W1/W2 in 64x64 tiles; 2: w (32-row cells); 3: chunk partials (chunk, 128-column cell); 4: diag(L) (128-row
+  // cells); 5: per-block sums.  All share one table of nt64 x nt64 cells (the 1-D ones use column 0).
+  constexpr int NBUF = 6;
+  std::vector<Cell> cells[NBUF];
+  for (int b = 0; b < NBUF; ++b) cells[b].resize((size_t)nt64 * nt64);
   std::vector<std::vector<uint64_t>> known(nt);
   auto hb = [&](int a, int b) -> bool {  // task a happened before task b starts
     for (int q = 0; q < DAG_MAXSIG; ++q) {
@@ -419,10 +484,33 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
       for (int r = r0 / 64; r < (r1 + 63) / 64; ++r)
         for (int c = c0 / 64; c < (c1 + 63) / 64; ++c) accs.push_back({bufi, r, c, write});
     };
+    auto cell = [&](int bufi, int r, int c, bool write) { accs.push_back({bufi, r, c, write}); };
     if (t.kind == DAG_LEAF) {
       const int b = t.row0 * 128;
       rect(0, b, b + 128, b, b + 128, false);
       rect(1, b, b + 128, b, b + 128, true);
+      cell(4, t.row0, 0, true);
+    } else if (t.kind == DAG_KMAT) {
+      for (int h = 0; h < 2; ++h)
+        if (t.row0 + 64 * h >= t.col0) rect(0, t.row0 + 64 * h, t.row0 + 64 * h + 64, t.col0, t.col0 + 64, true);
+    } else if (t.kind == DAG_TRMV_N) {
+      rect(1, t.row0, t.row0 + 32, 0, t.row0 + 32, false);
+      cell(2, t.row0 / 32, 0, true);
+    } else if (t.kind == DAG_TRMV_T) {
+      const int np = nblocks_total * 128, i0 = t.row0 * 256, i1 = std::min(i0 + 256, np);
+      for (int r = i0 / 64; r < i1 / 64; ++r)
+        for (int c = t.col0 / 64; c < t.col0 / 64 + 2; ++c)
+          if (r >= c) cell(1, r, c, false);
+      for (int q = i0 / 32; q < i1 / 32; ++q) cell(2, q, 0, false);
+      cell(3, t.row0, t.col0 / 128, true);
+    } else if (t.kind == DAG_ALPHA_REDUCE) {
+      const int np = nblocks_total * 128, nchunks = (np + 255) / 256;
+      for (int c = t.col0; c < nchunks; ++c)
+        for (int q = 2 * t.col0; q < 2 * t.col0 + 2 && q * 128 < np; ++q) cell(3, c, q, false);
+      for (int k = 2 * t.col0; k < 2 * t.col0 + 2 && k < nblocks_total; ++k) cell(4, k, 0, false);
+      cell(5, t.col0, 0, true);
+    } else if (t.kind == DAG_LML_FINAL) {
+      for (int b = 0; b < (nblocks_total * 128 + 255) / 256; ++b) cell(5, b, 0, false);
     } else {
       const int ta = t.kind == DAG_GEMM_128x64 ? 128 : 64, tb = 64;
       const int ab = (t.flags & DAGF_ABUF) ? 1 : 0, bb = (t.flags & DAGF_BBUF) ? 1 : 0, cb = (t.flags & DAGF_CBUF) ? 1 : 0;
@@ -437,6 +525,10 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     for (const Acc& a : accs) {
       if (a.r >= nt64 || a.c >= nt64 || a.r < 0 || a.c < 0) return "tile outside the matrix";
       Cell& cell = cells[a.buf][(size_t)a.r * nt64 + a.c];
+      if (a.buf >= 2 && !a.write && cell.writer < 0) {
+        snprintf(buf, sizeof buf, "task %d reads cell (%d,%d) of buffer %d that no earlier task has written", i, a.r, a.c, a.buf);
+        return buf;
+      }
       if (cell.writer >= 0 && cell.writer != i && !hb(cell.writer, i)) {
         snprintf(buf, sizeof buf, "task %d %s tile (%d,%d) of W%d written by task %d without waiting for it", i,
                  a.write ? "overwrites" : "reads", a.r, a.c, a.buf + 1, cell.writer);

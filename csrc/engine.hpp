@@ -70,7 +70,16 @@ struct GemmLaunch {
 // (dag_kernel.inc.hpp; plan built on the host by dag_plan.hpp).  A task waits until its counters have reached their
 // values, runs, publishes its results write-through and bumps its own counter.  The queue order is a topological
 // order of the dependency graph, so any number of resident workgroups >= 1 makes progress (no co-residency needed).
-enum : uint16_t { DAG_GEMM_128x64 = 0, DAG_GEMM_64x64 = 1, DAG_LEAF = 2 };
+enum : uint16_t {
+  DAG_GEMM_128x64 = 0, DAG_GEMM_64x64 = 1, DAG_LEAF = 2,
+  // the launches around the factorisation, as tasks of the same queue (same per-element arithmetic as the kernels they
+  // replace, so results stay bitwise equal): kernel-matrix tiles in front, the alpha / lml reductions behind
+  DAG_KMAT = 3,          // row0 = first row of a 128-row block, col0 = first column of a 64-column tile
+  DAG_TRMV_N = 4,        // row0 = first of 32 rows of w = X y
+  DAG_TRMV_T = 5,        // row0 = 256-row chunk index, col0 = first of 128 columns of the chunk's partial X^T w
+  DAG_ALPHA_REDUCE = 6,  // col0 = 256-column block index: alpha, partial sums of y^T alpha and log diag(L)
+  DAG_LML_FINAL = 7,
+};
 enum : uint16_t {
   DAGF_ABUF = 1,   // operand A lives in W2 (else W1)
   DAGF_BBUF = 2,
@@ -106,6 +115,15 @@ struct DagLaunch {
   int ld;
   void* ldiag;
   int* info;
+  // operands of the kernel-matrix and alpha / lml tasks (null / unused in a factorisation-only plan)
+  const void* X;          // n x d features
+  const void* y;          // np targets (zero padded)
+  const EvalParams* P;
+  int n, d, nu2;
+  void* wbuf;             // w = X y (np)
+  double* part_t;         // chunk partials of X^T w, then the per-block sums (as launch_alpha_lml lays them out)
+  void* alpha;            // np
+  EvalOut* out;
   unsigned long long* trace;  // optional (diagnostics): per task [pulled, inputs ready, computed, published] on the 100 MHz clock, then the CU id
 };
 template <typename T>

@@ -304,6 +304,7 @@ struct Slot {
   int best_run = 0, best_eval = 0;
   std::vector<double> best_theta;
   int last_target = 0;  // buffer written by the most recent evaluation
+  int dag_target = 0;   // alpha buffer the task-queue launch writes (its alpha / lml tasks)
   int gemm_ord = 0;     // ordinal of the next GEMM launch inside the current evaluation (indexes the static schedules)
 };
 
@@ -327,6 +328,7 @@ struct Problem : ProblemBase {
   std::vector<std::vector<Sched>> scheds;   // [device][gemm launch ordinal]
   // device-scheduled factorisation (dag_kernel.inc.hpp): one plan per problem, the same on every device
   bool dag_ = false;
+  bool dag_full_ = false;                   // the kernel-matrix tiles and the alpha / lml reductions are tasks of the queue too
   std::vector<DagTask*> dag_tasks;          // per device
   int dag_ntasks = 0, dag_nwg = 0;
   std::vector<DagTask> dag_host_tasks;      // kept for the trace dump
@@ -428,8 +430,14 @@ struct Problem : ProblemBase {
       dag_nwg = forced > 0 ? forced : std::max(1, cus / std::max(1, n_slots));
       // plans depend only on (blocks, stage depth, tiling and ordering knobs): the caller fits one model per generation with
       // slowly growing n, so they are kept (building + simulating the n=4096 queue costs ~15 ms of host time per fit)
+      // HBEGP_DAG_FULL=1: kmat and the alpha / lml reductions as tasks of the same queue instead of launches around it (under
+      // contention those launches take 0.11 + 0.28 ms per evaluation).  Bitwise the same results, but measured SLOWER: 1.485
+      // vs 1.524 fit+predict/s, 2.64 vs 2.55 ms for one evaluation alone -- one 512-thread workgroup per CU gives the fp64
+      // exp/sqrt code of the kernel-matrix tiles a quarter of the occupancy the launch has, and the alpha passes become a
+      // dependent tail on 85 CUs.  Off by default.
+      dag_full_ = env_int("HBEGP_DAG_FULL", 0) != 0;
       const std::array<int, 7> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
-                                      env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), 0};
+                                      env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0};
       static std::mutex cache_mu;
       static std::map<std::array<int, 7>, std::shared_ptr<const DagPlan>> cache;
       std::shared_ptr<const DagPlan> cached;
@@ -440,7 +448,7 @@ struct Problem : ProblemBase {
       }
       if (!cached) {
         DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5]);
-        cached = std::make_shared<const DagPlan>(builder.build(0, np / NB));
+        cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_));
         std::lock_guard<std::mutex> lk(cache_mu);
         if (cache.size() > 64) cache.clear();
         cache[key] = cached;
@@ -656,6 +664,8 @@ struct Problem : ProblemBase {
       DagLaunch g{};
       g.tasks = dag_tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
       g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
+      g.X = Xd[di]; g.y = yd[di]; g.P = s.dP; g.n = n; g.d = d; g.nu2 = nu2;
+      g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
       g.trace = s.dag_trace;
       if (tm) tm->begin(PhaseTimer::DAG, 0, dag_gflop);
       launch_dag<T>(g, dag_nwg, s.stream);
@@ -732,15 +742,19 @@ struct Problem : ProblemBase {
     const int nb = np / NB;
     s.gemm_ord = 0;
     const int* info = &s.dOut->info;
+    const bool in_queue = dag_ && dag_full_ && !adhoc_;  // kmat and alpha / lml run as tasks of the factorisation's queue
     if (!dry_) {
       HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
       launch_reset_out(s.dOut, s.stream);
-      if (tm) tm->begin(PhaseTimer::KMAT);
-      launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
-      if (tm) tm->end();
+      if (!in_queue) {
+        if (tm) tm->begin(PhaseTimer::KMAT);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+        if (tm) tm->end();
+      }
     }
+    s.dag_target = target;
     chol_inv(s, di, nb, tm);
-    if (!dry_) {
+    if (!dry_ && !in_queue) {
       if (tm) tm->begin(PhaseTimer::ALPHA);
       launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);
       if (tm) tm->end();
@@ -775,7 +789,12 @@ struct Problem : ProblemBase {
     s.gemm_ord = 0;
     HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
     launch_reset_out(s.dOut, s.stream);
-    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+    if (dag_ && dag_full_ && !adhoc_) {
+      // the queue also carries the alpha / lml tasks: let them write the alpha buffer that does NOT hold the captured best
+      s.dag_target = s.best_idx < 0 ? 1 - s.last_target : 1 - s.best_idx;
+    } else {
+      launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+    }
     chol_inv(s, di, np / NB, nullptr);
     CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
@@ -1773,8 +1792,8 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
                          double* gflop, double* crit_us, double* sim_us, char* err, int errlen) {
   if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0 || nwg < 0) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
-  DagBuilder builder(bk, small_h, nwg, fine != 0);
-  DagPlan plan = builder.build(0, nblocks);
+  DagBuilder builder(bk, small_h, nwg, (fine & 1) != 0);
+  DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0);  // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too
   // fault injection for the validator's own test: HBEGP_DAG_TEST_FAULT = "drop:<i>" (task i loses its first wait) or
   // "move:<i>:<j>" (task i is moved to queue position j)
   if (const char* fault = getenv("HBEGP_DAG_TEST_FAULT")) {

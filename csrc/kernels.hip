@@ -690,7 +690,7 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
           T dv = T(0);
 #pragma unroll
           for (int j = 0; j < 16; ++j) dv = (j == lane) ? a[j] : dv;
-          ldiag[blk * NB + p * 16 + lane] = (TIO)dv;
+          gstore<SC1>(&ldiag[blk * NB + p * 16 + lane], (TIO)dv);  // read by the alpha tasks of the same launch
           Rd[p * 16 + lane] = rinv_own;
         }
         if (bad && lane == 0 && !helper) atomicCAS(info, 0, 1 + blk * NB + p * 16);
@@ -882,7 +882,8 @@ __global__ void __launch_bounds__(256) trmv_n_kernel(const T* __restrict__ Xinv,
   if (row >= np) return;
   double acc = 0;
   const T* xr = Xinv + (size_t)row * np;
-  for (int k = lane; k <= row && k < n; k += 64) acc += (double)xr[k] * (double)y[k];
+  // explicit fma: dag_trmv_n (dag_kernel.inc.hpp) repeats this sum and must round the same way wherever it is inlined
+  for (int k = lane; k <= row && k < n; k += 64) acc = __builtin_fma((double)xr[k], (double)y[k], acc);
   acc = wave_sum(acc);
   if (lane == 0) w[row] = (T)acc;
 }
@@ -899,7 +900,7 @@ __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv,
   const int i_begin = chunk * 256, i_end = min(i_begin + 256, np);
   if (i_end > blockIdx.x * 64) {
     for (int i = i_begin + sgrp; i < i_end; i += 4)
-      if (i >= j) acc += (double)Xinv[(size_t)i * np + j] * (double)w[i];
+      if (i >= j) acc = __builtin_fma((double)Xinv[(size_t)i * np + j], (double)w[i], acc);
   }
   red[sgrp][c] = acc;
   __syncthreads();
@@ -944,7 +945,7 @@ __global__ void lml_final_kernel(const double* __restrict__ sums, int nblocks, i
     }
     out->yalpha = s1;
     out->logdet = s2;
-    out->lml = -0.5 * s1 - s2 - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
+    out->lml = __builtin_fma(-0.5, s1, -s2) - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
     atomicOr(&out->done, 1);
   }
 }
