@@ -54,7 +54,11 @@ inline int dag_split_point(int lo, int hi) {
 }
 
 struct DagPlan {
-  std::vector<DagTask> tasks;
+  std::vector<DagTask> tasks;   // one topological order of everything (what dag_plan_validate checks)
+  // split launches (DagBuilder::nchain > 0): the same order, dealt into the two kernels' queues
+  std::vector<DagTask> chain;   // the diagonal blocks
+  std::vector<DagTask> bulk;    // the tile tasks
+  int n_prio = 0;               // tile tasks marked DAGF_PRIO
   std::vector<int> totals;  // per counter: number of tasks that bump it
   double gflop = 0;         // algorithmic flops of the tile products (2*128^3 per pair of 128-blocks, half on triangles)
   int n_leaf = 0;
@@ -84,8 +88,13 @@ class DagBuilder {
   // nwg: workgroups the queue is ordered for (0: keep the recursion's order)
   // crit_rows: in the big nodes, this many block rows next to the diagonal chain (the first rows of T and of the Schur
   //            update, the last rows of X21) also use 64x64 tiles: they sit on the critical path, where a tile's time counts
-  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true, int crit_rows = 1)
-      : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine), crit_rows_(crit_rows) {}
+  // nchain > 0: split launches -- the diagonal blocks form the chain kernel's queue (nchain workers in the simulated
+  //   schedule, which only they serve), everything else the bulk kernel's (nwg workers); tile tasks whose slack against the
+  //   critical path is below prio_slack_us get DAGF_PRIO
+  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true, int crit_rows = 1, int nchain = 0, double prio_slack_us = 0,
+             double bulk_scale = 1.0)
+      : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine), crit_rows_(crit_rows), nchain_(nchain), prio_slack_(prio_slack_us),
+        bulk_scale_(bulk_scale) {}
 
   // full = true: the kernel-matrix tiles in front of the recursion and the alpha / lml reductions behind it are tasks of the
   // same queue (whole matrix only: blo = 0, bhi = np / 128)
@@ -100,6 +109,10 @@ class DagBuilder {
     for (int tot : plan_.totals)
       if (tot > 0xffff) plan_.tasks.clear();
     if (nwg_ > 0 && !plan_.tasks.empty()) order();
+    if (nchain_ > 0) {
+      if (full) plan_.tasks.clear();  // the kernel-matrix / reduction tasks need the whole LDS: no split form
+      for (const DagTask& t : plan_.tasks) (t.kind == DAG_LEAF ? plan_.chain : plan_.bulk).push_back(t);
+    }
     return plan_;
   }
 
@@ -107,6 +120,8 @@ class DagBuilder {
   int bk_, small_h_, nwg_;
   bool fine_;
   int crit_rows_ = 1;
+  int nchain_ = 0;
+  double prio_slack_ = 0, bulk_scale_ = 1.0;
   DagPlan plan_;
   DagCosts cost_;
 
@@ -365,6 +380,20 @@ class DagBuilder {
       for (int w = 0; w < t.nwait; ++w) blc[t.wcnt[w]] = std::max(blc[t.wcnt[w]], bl[i]);
     }
     plan_.crit_us = *std::max_element(bl.begin(), bl.end());
+    if (nchain_ > 0 && prio_slack_ > 0) {
+      // top levels (earliest start with unlimited workers): emission order is topological, one forward sweep
+      std::vector<double> tl(nt, 0.0), ready_at(nc, 0.0);
+      for (int i = 0; i < nt; ++i) {
+        DagTask& t = plan_.tasks[i];
+        for (int w = 0; w < t.nwait; ++w) tl[i] = std::max(tl[i], ready_at[t.wcnt[w]]);
+        for (int q = 0; q < DAG_MAXSIG; ++q)
+          if (t.sig[q] != DAG_NOSIG) ready_at[t.sig[q]] = std::max(ready_at[t.sig[q]], tl[i] + t.cost * 0.1);
+        if (t.kind != DAG_LEAF && plan_.crit_us - (tl[i] + bl[i]) < prio_slack_) {
+          t.flags |= DAGF_PRIO;
+          plan_.n_prio++;
+        }
+      }
+    }
     if (getenv("HBEGP_DAG_DUMP")) {  // the critical path, task by task (diagnostics)
       int cur = (int)(std::max_element(bl.begin(), bl.end()) - bl.begin());
       double acc_leaf = 0, acc_small = 0, acc_big = 0;
@@ -385,37 +414,41 @@ class DagBuilder {
     }
     std::vector<int> count(nc, 0), missing(nt, 0);
     typedef std::pair<double, int> Pri;  // (bottom level, -index): highest first, earlier emission breaks ties
-    std::priority_queue<Pri> ready;
+    // worker class 0: the (bulk) workgroups; class 1: the chain kernel's, which serve the diagonal blocks and nothing else
+    std::priority_queue<Pri> ready[2];
+    auto cls = [&](int i) { return (nchain_ > 0 && plan_.tasks[i].kind == DAG_LEAF) ? 1 : 0; };
     for (int i = 0; i < nt; ++i) {
       missing[i] = plan_.tasks[i].nwait;
-      if (missing[i] == 0) ready.push({bl[i], -i});
+      if (missing[i] == 0) ready[cls(i)].push({bl[i], -i});
     }
     typedef std::pair<double, int> Ev;  // (finish time, task)
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> running;
     std::vector<DagTask> out;
     out.reserve(nt);
-    int idle = nwg_;
+    int idle[2] = {nwg_, nchain_};
     double now = 0;
     while ((int)out.size() < nt) {
-      while (idle > 0 && !ready.empty()) {
-        const int i = -ready.top().second;
-        ready.pop();
-        out.push_back(plan_.tasks[i]);
-        running.push({now + plan_.tasks[i].cost * 0.1, i});
-        --idle;
-      }
+      for (int k = 0; k < 2; ++k)
+        while (idle[k] > 0 && !ready[k].empty()) {
+          const int i = -ready[k].top().second;
+          ready[k].pop();
+          out.push_back(plan_.tasks[i]);
+          const double scale = (k == 0 && nchain_ > 0 && !(plan_.tasks[i].flags & DAGF_PRIO)) ? bulk_scale_ : 1.0;
+          running.push({now + plan_.tasks[i].cost * 0.1 * scale, i});
+          --idle[k];
+        }
       if (running.empty()) break;  // cannot happen for a sound graph
       const Ev e = running.top();
       running.pop();
       now = e.first;
-      ++idle;
+      ++idle[cls(e.second)];
       const DagTask& t = plan_.tasks[e.second];
       for (int q = 0; q < DAG_MAXSIG; ++q) {
         if (t.sig[q] == DAG_NOSIG) continue;
         const int c = t.sig[q];
         if (++count[c] == plan_.totals[c])
           for (int wtr : waiters[c])
-            if (--missing[wtr] == 0) ready.push({bl[wtr], -wtr});
+            if (--missing[wtr] == 0) ready[cls(wtr)].push({bl[wtr], -wtr});
       }
     }
     while (!running.empty()) { now = running.top().first; running.pop(); }

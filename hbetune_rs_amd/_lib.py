@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhbegp.so")
+LIB_PATH = os.environ.get("HBEGP_LIB") or os.path.join(HERE, "libhbegp.so")  # HBEGP_LIB: an experimental build of the same library
 
 OK, NOT_PD, ALL_FAILED = 0, 1, 2
 EINVAL, EHIP, ENODEV, ENOMEM = -1, -2, -3, -4
