@@ -44,7 +44,7 @@ static_assert(DAG_LDS_BYTES <= 163840, "the diagonal block and the control words
 
 template <typename T, int TA, int TB>
 __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int kbeg, int kend, T* __restrict__ W1,
-                                              T* __restrict__ W2, int ld, char* smem_raw) {
+                                              T* __restrict__ W2, T* __restrict__ W3, T* __restrict__ Kinv, int ld, char* smem_raw) {
   using C = Cfg<T>;
   using G = DagGeom<T, TA, TB>;
   using vec_t = typename C::vec_t;
@@ -53,9 +53,9 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   constexpr int TMA = G::TMA, TMB = G::TMB, NT = G::NT;
 
   const int akm = (flags & DAGF_AKM) ? 1 : 0, bkm = (flags & DAGF_BKM) ? 1 : 0;
-  const T* Ag = (flags & DAGF_ABUF) ? W2 : W1;
-  const T* Bg = (flags & DAGF_BBUF) ? W2 : W1;
-  T* Cg = (flags & DAGF_CBUF) ? W2 : W1;
+  const T* Ag = (flags & DAGF_A3) ? W3 : ((flags & DAGF_ABUF) ? W2 : W1);
+  const T* Bg = (flags & DAGF_B3) ? W3 : ((flags & DAGF_BBUF) ? W2 : W1);
+  T* Cg = (flags & DAGF_CKINV) ? Kinv : ((flags & DAGF_C3) ? W3 : ((flags & DAGF_CBUF) ? W2 : W1));
   const int nstages = (kend - kbeg) / BK;
 
   T* lds = reinterpret_cast<T*>(smem_raw);  // [A buf0 | A buf1 | B buf0 | B buf1]
@@ -98,6 +98,23 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   for (int a = 0; a < TMA; ++a)
 #pragma unroll
     for (int b = 0; b < TMB; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+  // beta = 1: the old values of the output tile are fetched now and added in the epilogue (same arithmetic as loading them
+  // there; the loads' latency hides under the contraction -- it was a third of a 128-deep update's time)
+  // Only for the 64x64 tile (8 registers): with 16 more in the 128x64 tile the kernel's diagonal block spills, and that
+  // tile's contractions are deep enough for the late load not to matter.
+  const bool accum = (flags & DAGF_ACC) != 0;
+  constexpr bool PREFETCH_C = TA == 64;
+  T cold[PREFETCH_C ? TMA : 1][PREFETCH_C ? TMB : 1][4];
+  if constexpr (PREFETCH_C) {
+    const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
+#pragma unroll
+    for (int a = 0; a < TMA; ++a)
+#pragma unroll
+      for (int b = 0; b < TMB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cold[a][b][r] = accum ? Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16] : T(0);
+  }
 
   // f32: fp64 totals per F32_CHUNK contraction elements, exactly as gemm_kernel does (same chunk boundaries: same bits)
   constexpr bool CHUNKED = sizeof(T) == 4;
@@ -186,7 +203,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 
   // epilogue: write-through stores (read by other workgroups of this launch)
   const int er0 = row0 + wm * (TA / G::WM), ec0 = col0 + wn * (TB / G::WN) + (lane & 15);
-  const bool neg = (flags & DAGF_NEG) != 0, accum = (flags & DAGF_ACC) != 0;
+  const bool neg = (flags & DAGF_NEG) != 0;
 #pragma unroll
   for (int a = 0; a < TMA; ++a)
 #pragma unroll
@@ -199,7 +216,11 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
         if constexpr (CHUNKED) v = (T)tot[a][b][r];
         else v = acc[a][b][r];
         if (neg) v = -v;
-        if (accum) v += *p;
+        if constexpr (PREFETCH_C) {
+          if (accum) v += cold[a][b][r];
+        } else {
+          if (accum) v += *p;
+        }
         gstore<true>(p, v);
       }
 }
@@ -387,41 +408,43 @@ __device__ __forceinline__ bool dag_wait(int* ctrl, int* info, int cnt, int val,
   }
 }
 
-// LDS of a bulk workgroup: the larger of the two tile geometries' double-buffered stages, then the control words
+// The diagonal block as a function of its own (DAG_LEAF_NOINLINE): its register allocation then does not compete with the
+// tile pipeline's inside one kernel body.
+#ifndef DAG_LEAF_NOINLINE
+#define DAG_LEAF_NOINLINE 0
+#endif
 template <typename T>
-constexpr int dag_gemm_lds_bytes() {
-  return (int)(sizeof(T) * 2 * (DagGeom<T, 128, 64>::LDSA + DagGeom<T, 128, 64>::LDSB));
+#if DAG_LEAF_NOINLINE
+__device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
+#else
+__device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
+#endif
+  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, smem_raw);
 }
-constexpr int DAG_BULK_CTL_OFF =
-    ((dag_gemm_lds_bytes<double>() > dag_gemm_lds_bytes<float>() ? dag_gemm_lds_bytes<double>() : dag_gemm_lds_bytes<float>()) + 15) / 16 * 16;
-constexpr int DAG_BULK_LDS_BYTES = DAG_BULK_CTL_OFF + 128;
-static_assert(2 * DAG_BULK_LDS_BYTES <= 163840, "two bulk workgroups must fit one CU's LDS");
 
-// MODE = DAG_MODE_ALL: every task kind, workgroups with the whole LDS pull from one queue.
-// MODE = DAG_MODE_BULK: tile tasks only (the queue holds nothing else), DAG_BULK_LDS_BYTES of LDS: two workgroups per CU.
-// MODE = DAG_MODE_CHAIN: one workgroup (of the chain server) walks a slot's chain queue -- the diagonal blocks -- in order.
-// `next`: thread 0's index of the first task (ALL / BULK: pulled from the queue head by the caller).
 template <typename T, int MODE>
-__device__ __forceinline__ void dag_loop(const DagLaunch& g, char* smem_raw, int next) {
-  constexpr int CTL_OFF = MODE == DAG_MODE_BULK ? DAG_BULK_CTL_OFF : DAG_LDS_CTL_OFF;
-  int* ctl = reinterpret_cast<int*>(smem_raw + CTL_OFF);  // [0] task index, [1] 0 run / 1 skip / 2 leave, [4..15] the task
+__global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
+  extern __shared__ __align__(16) char smem_raw[];
+  int* ctl = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);  // [0] task index, [1] 0 run / 1 skip / 2 leave, [4..15] the task
   const int t = threadIdx.x;
   T* W1 = static_cast<T*>(g.W1);
   T* W2 = static_cast<T*>(g.W2);
   constexpr int TASK_DW = (int)(sizeof(DagTask) / 4);
+  int next = 0;  // thread 0: index of the task pulled for the next round
+  if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (;;) {
     if (t < 64) {
       // wave 0: stage the task descriptor in LDS (one load instruction), then lane 0 waits for its dependencies
       const int idx = __builtin_amdgcn_readfirstlane(next);
       int status = idx >= g.ntasks ? 2 : 0;
-      if (g.trace && t == 0 && status == 0) g.trace[(size_t)(g.trace_base + idx) * 5 + 0] = __builtin_amdgcn_s_memrealtime();
+      if (g.trace && t == 0 && status == 0) g.trace[(size_t)idx * 5 + 0] = __builtin_amdgcn_s_memrealtime();
       if (status == 0) {
         if (t < TASK_DW) ctl[4 + t] = reinterpret_cast<const int*>(g.tasks + idx)[t];
         if (t == 0) {
           const DagTask* tk = reinterpret_cast<const DagTask*>(ctl + 4);  // same wave: LDS accesses are in order
           const int nw = tk->nwait;
           for (int w = 0; w < nw && status == 0; ++w)
-            if (!dag_wait(g.ctrl, g.info, tk->wcnt[w], tk->wval[w], g.trace_base + idx)) status = 2;
+            if (!dag_wait(g.ctrl, g.info, tk->wcnt[w], tk->wval[w], idx)) status = 2;
           if (status == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines: operands were written by other CUs
             const int inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -433,7 +456,7 @@ __device__ __forceinline__ void dag_loop(const DagLaunch& g, char* smem_raw, int
         ctl[0] = idx;
         ctl[1] = status;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the barrier below must not open before the invalidate is complete
-        if (g.trace && status != 2) g.trace[(size_t)(g.trace_base + idx) * 5 + 1] = __builtin_amdgcn_s_memrealtime();
+        if (g.trace && status != 2) g.trace[(size_t)idx * 5 + 1] = __builtin_amdgcn_s_memrealtime();
       }
     }
     __syncthreads();
@@ -444,170 +467,65 @@ __device__ __forceinline__ void dag_loop(const DagLaunch& g, char* smem_raw, int
     const int kind = kf & 0xffff, flags = (kf >> 16) & 0xffff;
     const int row0 = __builtin_amdgcn_readfirstlane(ctl[5]), col0 = __builtin_amdgcn_readfirstlane(ctl[6]);
     const int kbeg = __builtin_amdgcn_readfirstlane(ctl[7]), kend = __builtin_amdgcn_readfirstlane(ctl[8]);
-    const int sig0 = (__builtin_amdgcn_readfirstlane(ctl[9]) >> 16) & 0xffff, sig1 = __builtin_amdgcn_readfirstlane(ctl[10]) & 0xffff;
+    const int sig0 = (__builtin_amdgcn_readfirstlane(ctl[9]) >> 16) & 0xffff, sig12 = __builtin_amdgcn_readfirstlane(ctl[10]);
+    const int sig1 = sig12 & 0xffff, sig2 = (sig12 >> 16) & 0xffff;
     if (status == 0) {
-      if constexpr (MODE == DAG_MODE_CHAIN) {
-        if (kind == DAG_LEAF) leaf_body<double, T, true>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, 0, smem_raw);
-      } else if constexpr (MODE == DAG_MODE_BULK) {
-        const bool prio = (flags & DAGF_PRIO) != 0;
-        if (prio) __builtin_amdgcn_s_setprio(3);
-        if (kind == DAG_GEMM_128x64) dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
-        else if (kind == DAG_GEMM_64x64) dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
-        if (prio) __builtin_amdgcn_s_setprio(0);
-      } else {
-        if (kind == DAG_LEAF) {
-          leaf_body<double, T, true>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, 0, smem_raw);
-        } else if (kind == DAG_GEMM_128x64) {
-          dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
-        } else if (kind == DAG_GEMM_64x64) {
-          dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, g.ld, smem_raw);
-        } else if constexpr (MODE == DAG_MODE_FULL) {
-          // (a separate instantiation: with these inlined into the common kernel the diagonal block spilled 60 VGPRs)
-          if (kind == DAG_KMAT) {
-            dag_kmat_tile<T>(g, row0, col0, W1, smem_raw);
-          } else if (kind == DAG_TRMV_N) {
-            dag_trmv_n<T>(g, row0, W2);
-          } else if (kind == DAG_TRMV_T) {
-            dag_trmv_t<T>(g, row0, col0, W2, smem_raw);
-          } else if (kind == DAG_ALPHA_REDUCE) {
-            dag_alpha_reduce<T>(g, col0, smem_raw);
-          } else if (kind == DAG_LML_FINAL) {
-            dag_lml_final(g);
-          }
+      if (kind == DAG_LEAF) {
+        dag_leaf_task<T>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, smem_raw);
+      } else if ((flags & DAGF_CKINV) && g.Kinv == nullptr) {
+        // factorisation-only launch: the K^-1 tiles are not wanted
+      } else if (kind == DAG_GEMM_128x64) {
+        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw);
+      } else if (kind == DAG_GEMM_64x64) {
+        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw);
+      } else if constexpr (MODE == DAG_MODE_FULL) {
+        if (kind == DAG_KMAT) {
+          dag_kmat_tile<T>(g, row0, col0, W1, smem_raw);
+        } else if (kind == DAG_TRMV_N) {
+          dag_trmv_n<T>(g, row0, W2);
+        } else if (kind == DAG_TRMV_T) {
+          dag_trmv_t<T>(g, row0, col0, W2, smem_raw);
+        } else if (kind == DAG_ALPHA_REDUCE) {
+          dag_alpha_reduce<T>(g, col0, smem_raw);
+        } else if (kind == DAG_LML_FINAL) {
+          dag_lml_final(g);
         }
       }
     }
     const int cur_idx = __builtin_amdgcn_readfirstlane(ctl[0]);
-    if (g.trace && t == 0) g.trace[(size_t)(g.trace_base + cur_idx) * 5 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (g.trace && t == 0) g.trace[(size_t)cur_idx * 5 + 2] = __builtin_amdgcn_s_memrealtime();
     // pull the next task while this one's stores drain (the workgroup still runs its tasks in queue order)
-    if constexpr (MODE == DAG_MODE_CHAIN) {
-      if (t == 0) next = cur_idx + 1;
-    } else {
-      if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // publish: every wave drains its write-through stores, then lanes of ONE wave bump the counters
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
-      const int mysig = t == 0 ? sig0 : sig1;
+      const int mysig = t == 0 ? sig0 : (t == 1 ? sig1 : sig2);
       if (t < DAG_MAXSIG && mysig != DAG_NOSIG)
         __hip_atomic_fetch_add(g.ctrl + DAG_CTRL_WORDS + mysig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (g.trace && t == 0) {
-        g.trace[(size_t)(g.trace_base + cur_idx) * 5 + 3] = __builtin_amdgcn_s_memrealtime();
+        g.trace[(size_t)cur_idx * 5 + 3] = __builtin_amdgcn_s_memrealtime();
         unsigned xcc = 0, hwid = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g.trace[(size_t)(g.trace_base + cur_idx) * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+        g.trace[(size_t)cur_idx * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
       }
     }
   }
-}
-
-template <typename T, int MODE>
-#ifndef DAG_BULK_WAVES
-#define DAG_BULK_WAVES 4
-#endif
-__global__ void __launch_bounds__(512, MODE == DAG_MODE_BULK ? DAG_BULK_WAVES : 2) dag_kernel(DagLaunch g) {
-  extern __shared__ __align__(16) char smem_raw[];
-  int next = 0;
-  if (threadIdx.x == 0) {
-    next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // split launches: whoever pulls task 0 tells the chain server that this evaluation's counters are cleared and its
-    // kernel matrix is in place (both precede this launch in stream order)
-    if (MODE == DAG_MODE_BULK && next == 0 && g.go) __hip_atomic_fetch_add(g.go, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  dag_loop<T, MODE>(g, smem_raw, next);
-}
-
-// The chain server: a persistent launch of DAG_MAX_SERVED workgroups with the whole LDS, on CUs reserved for it (one per
-// XCC, CU-masked stream), alive while a problem with split launches lives.  A workgroup scans the board for a slot whose
-// bulk launches (go) outnumber the chains started on it (claimed), claims the evaluation with one compare-and-swap and
-// walks the slot's diagonal blocks; then it scans again.  It leaves when the host sets quit, or -- so that no host failure
-// can leave it spinning -- after DAG_SERVER_IDLE_TICKS without work (the host restarts a server it has not used for a
-// while before relying on it, hbegp.cpp ensure_server).
-template <typename T>
-__global__ void __launch_bounds__(512, 2) chain_server_kernel(DagBoard* B) {
-  extern __shared__ __align__(16) char smem_raw[];
-  int* ctl = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);
-  const int t = threadIdx.x;
-  if (t == 0) __hip_atomic_fetch_add(&B->alive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long t_last = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
-    if (t == 0) {
-      int found = -1;
-      const int ns = B->nslots;
-      for (int s = 0; s < ns && found < 0; ++s) {
-        const int done = __hip_atomic_load(&B->claimed[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int go = __hip_atomic_load(B->slot[s].go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (go - done > 0) {
-          int expected = done;
-          if (__hip_atomic_compare_exchange_strong(&B->claimed[s], &expected, done + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            found = s;
-        }
-      }
-      if (found < 0) {
-        if (__hip_atomic_load(&B->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) found = -2;
-        else if (__builtin_amdgcn_s_memrealtime() - t_last > DAG_SERVER_IDLE_TICKS) found = -2;
-        else __builtin_amdgcn_s_sleep(4);
-      }
-      ctl[2] = found;
-    }
-    __syncthreads();
-    const int slot = __builtin_amdgcn_readfirstlane(ctl[2]);
-    __syncthreads();  // ctl[2] is rewritten in the next round
-    if (slot == -2) break;
-    if (slot < 0) continue;
-    const DagServed& sv = B->slot[slot];
-    DagLaunch g{};
-    g.tasks = sv.tasks; g.ntasks = sv.ntasks; g.mode = DAG_MODE_CHAIN; g.go = sv.go; g.ctrl = sv.ctrl;
-    g.W1 = sv.W1; g.W2 = sv.W2; g.ld = sv.ld; g.ldiag = sv.ldiag; g.info = sv.info;
-    g.trace = sv.trace; g.trace_base = sv.trace_base;
-    dag_loop<T, DAG_MODE_CHAIN>(g, smem_raw, 0);
-    __syncthreads();
-    t_last = __builtin_amdgcn_s_memrealtime();
-  }
-  if (t == 0) __hip_atomic_fetch_add(&B->alive, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T>
 void launch_dag(const DagLaunch& g, int nwg, hipStream_t s) {
   if (g.ntasks <= 0 || nwg <= 0) return;
-  if (g.mode == DAG_MODE_BULK) hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_BULK>), dim3(nwg), dim3(512), DAG_BULK_LDS_BYTES, s, g);
-  else if (g.mode == DAG_MODE_FULL) hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_FULL>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
-  else hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_ALL>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
+  if (g.mode == DAG_MODE_FULL) hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_FULL>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
+  else hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_FACTOR>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
 }
 template void launch_dag<double>(const DagLaunch&, int, hipStream_t);
 template void launch_dag<float>(const DagLaunch&, int, hipStream_t);
 
-template <typename T>
-void launch_chain_server(DagBoard* board, int nwg, hipStream_t s) {
-  hipLaunchKernelGGL((chain_server_kernel<T>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, board);
-}
-template void launch_chain_server<double>(DagBoard*, int, hipStream_t);
-template void launch_chain_server<float>(DagBoard*, int, hipStream_t);
-
-__global__ void whereami_kernel(unsigned* out) {
-  extern __shared__ __align__(16) char smem_raw[];
-  if (threadIdx.x == 0) {
-    unsigned xcc = 0, hwid = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    out[blockIdx.x] = ((xcc & 0xf) << 16) | ((hwid >> 8) & 0xff);
-    if (hwid == 0xffffffffu) smem_raw[0] = 1;  // keep the dynamic LDS referenced
-  }
-}
-void launch_whereami(unsigned* out, int nwg, int lds_bytes, hipStream_t s) {
-  hipLaunchKernelGGL(whereami_kernel, dim3(nwg), dim3(512), lds_bytes, s, out);
-}
-
 static void init_dag_kernels() {
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_ALL>), DAG_LDS_BYTES, "dag_kernel<f64>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float, DAG_MODE_ALL>), DAG_LDS_BYTES, "dag_kernel<f32>: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_FACTOR>), DAG_LDS_BYTES, "dag_kernel<f64>: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float, DAG_MODE_FACTOR>), DAG_LDS_BYTES, "dag_kernel<f32>: dynamic LDS limit");
   set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_FULL>), DAG_LDS_BYTES, "dag_kernel<f64, full>: dynamic LDS limit");
   set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float, DAG_MODE_FULL>), DAG_LDS_BYTES, "dag_kernel<f32, full>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&chain_server_kernel<double>), DAG_LDS_BYTES, "chain_server_kernel<f64>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&chain_server_kernel<float>), DAG_LDS_BYTES, "chain_server_kernel<f32>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_BULK>), DAG_BULK_LDS_BYTES, "dag_kernel<f64, bulk>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float, DAG_MODE_BULK>), DAG_BULK_LDS_BYTES, "dag_kernel<f32, bulk>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&whereami_kernel), 163840, "whereami_kernel: dynamic LDS limit");
 }

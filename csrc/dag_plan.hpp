@@ -54,13 +54,11 @@ inline int dag_split_point(int lo, int hi) {
 }
 
 struct DagPlan {
-  std::vector<DagTask> tasks;   // one topological order of everything (what dag_plan_validate checks)
-  // split launches (DagBuilder::nchain > 0): the same order, dealt into the two kernels' queues
-  std::vector<DagTask> chain;   // the diagonal blocks
-  std::vector<DagTask> bulk;    // the tile tasks
-  int n_prio = 0;               // tile tasks marked DAGF_PRIO
+  std::vector<DagTask> tasks;
   std::vector<int> totals;  // per counter: number of tasks that bump it
   double gflop = 0;         // algorithmic flops of the tile products (2*128^3 per pair of 128-blocks, half on triangles)
+  double gflop_lauum = 0;   // of which: the K^-1 = X^T X tiles (lauum = true)
+  int n_lauum = 0;
   int n_leaf = 0;
   double sim_us = 0;        // makespan of the simulated schedule (estimate)
   double crit_us = 0;       // critical path of the graph under the same estimates
@@ -88,31 +86,33 @@ class DagBuilder {
   // nwg: workgroups the queue is ordered for (0: keep the recursion's order)
   // crit_rows: in the big nodes, this many block rows next to the diagonal chain (the first rows of T and of the Schur
   //            update, the last rows of X21) also use 64x64 tiles: they sit on the critical path, where a tile's time counts
-  // nchain > 0: split launches -- the diagonal blocks form the chain kernel's queue (nchain workers in the simulated
-  //   schedule, which only they serve), everything else the bulk kernel's (nwg workers); tile tasks whose slack against the
-  //   critical path is below prio_slack_us get DAGF_PRIO
-  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true, int crit_rows = 1, int nchain = 0, double prio_slack_us = 0,
-             double bulk_scale = 1.0)
-      : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine), crit_rows_(crit_rows), nchain_(nchain), prio_slack_(prio_slack_us),
-        bulk_scale_(bulk_scale) {}
+  DagBuilder(int bk, int small_h, int nwg = 0, bool fine = true, int crit_rows = 1)
+      : bk_(bk), small_h_(small_h), nwg_(nwg), fine_(fine), crit_rows_(crit_rows) {}
 
   // full = true: the kernel-matrix tiles in front of the recursion and the alpha / lml reductions behind it are tasks of the
   // same queue (whole matrix only: blo = 0, bhi = np / 128)
-  DagPlan build(int blo, int bhi, bool full = false) {
+  // right-looking plan: widest column range of a grouped update (measured at n = 4096, fit+predict/s: 4 -> 1.50, 8 -> 1.53,
+  // 16 -> 1.53, 32 -> 1.57) and how many block columns ahead of the chain are updated column by column (1 -> 1.57, 2 -> 1.53,
+  // 3 -> 1.51; one evaluation alone: 2.21 / 2.19 ms)
+  void set_rl(int group, int near) { rl_group_ = std::max(1, group); rl_near_ = std::max(1, near); }
+  // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
+  // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
+  // carries the inverse (whole matrix only; the factor L lives in W3)
+  DagPlan build(int blo, int bhi, bool full = false, bool lauum = false, bool rl = false) {
     plan_ = DagPlan();
-    if (full && blo == 0) {
+    top_lo_ = blo; top_hi_ = bhi;
+    if (rl && blo == 0 && !full) {
+      build_rl(bhi, lauum);
+    } else if (full && blo == 0) {
       build_full(bhi);
     } else {
-      rec(blo, bhi, nullptr);
+      const Sub root = rec(blo, bhi, nullptr);
+      if (lauum && blo == 0) build_lauum(bhi, root);
     }
     if (plan_.totals.size() >= 0xffff) plan_.tasks.clear();  // counter ids are 16-bit: the caller falls back
     for (int tot : plan_.totals)
       if (tot > 0xffff) plan_.tasks.clear();
     if (nwg_ > 0 && !plan_.tasks.empty()) order();
-    if (nchain_ > 0) {
-      if (full) plan_.tasks.clear();  // the kernel-matrix / reduction tasks need the whole LDS: no split form
-      for (const DagTask& t : plan_.tasks) (t.kind == DAG_LEAF ? plan_.chain : plan_.bulk).push_back(t);
-    }
     return plan_;
   }
 
@@ -120,8 +120,7 @@ class DagBuilder {
   int bk_, small_h_, nwg_;
   bool fine_;
   int crit_rows_ = 1;
-  int nchain_ = 0;
-  double prio_slack_ = 0, bulk_scale_ = 1.0;
+  int rl_group_ = 32, rl_near_ = 1;
   DagPlan plan_;
   DagCosts cost_;
 
@@ -129,7 +128,7 @@ class DagBuilder {
     plan_.totals.push_back(0);
     return (int)plan_.totals.size() - 1;
   }
-  void push(DagTask t, const std::vector<DagGate>& waits, int sig0, int sig1, double cost_us) {
+  void push(DagTask t, const std::vector<DagGate>& waits, int sig0, int sig1, double cost_us, int sig2 = -1) {
     t.nwait = 0;
     for (const DagGate& g : waits) {
       if (g.cnt < 0) continue;
@@ -142,6 +141,8 @@ class DagBuilder {
     }
     t.sig[0] = sig0 < 0 ? DAG_NOSIG : (uint16_t)sig0;
     t.sig[1] = sig1 < 0 ? DAG_NOSIG : (uint16_t)sig1;
+    t.sig[2] = sig2 < 0 ? DAG_NOSIG : (uint16_t)sig2;
+    if (sig2 >= 0) plan_.totals[sig2]++;
     if (sig0 >= 0) plan_.totals[sig0]++;
     if (sig1 >= 0) plan_.totals[sig1]++;
     t.cost = (uint16_t)std::min(65535.0, cost_us * 10.0);
@@ -169,11 +170,12 @@ class DagBuilder {
         const bool diag = op.lower && bi == bj;
         for (int hj = 0; hj < 2; ++hj) {
           const int tj = 2 * bj + hj;  // 64-column unit
-          auto krange = [&](int ti_last, int* ka, int* kb) {
+          auto krange = [&](int ti_last, int ti_first, int* ka, int* kb) {
             *ka = 2 * op.k0; *kb = 2 * op.k1;
             if (op.klim == 1) *kb = std::min(*kb, tj + 1);
             if (op.klim == 2) *ka = std::max(*ka, tj);
             if (op.klim == 3) *kb = std::min(*kb, ti_last + 1);
+            if (op.klim == 4) *ka = std::max(*ka, ti_first);
           };
           const bool crit_row = (op.crit == 1 && bi < op.r0 + crit_rows_) || (op.crit == 2 && bi >= op.r1 - crit_rows_);
           if (small || diag || crit_row) {
@@ -181,12 +183,12 @@ class DagBuilder {
               const int ti = 2 * bi + hi;
               if (diag && ti < tj) continue;  // strictly upper 64-tile of a symmetric result
               int ka, kb;
-              krange(ti, &ka, &kb);
+              krange(ti, ti, &ka, &kb);
               tiles.push_back({DAG_GEMM_64x64, bi, bj, ti * 64, tj * 64, ka * 64, kb * 64});
             }
           } else {
             int ka, kb;
-            krange(2 * bi + 1, &ka, &kb);  // the tile's lower 64 rows decide; the extra range of the upper rows meets zeros
+            krange(2 * bi + 1, 2 * bi, &ka, &kb);  // klim 3: the tile's lower 64 rows decide, klim 4: its upper 64 rows; the extra range of the other half meets zeros
             tiles.push_back({DAG_GEMM_128x64, bi, bj, bi * 128, tj * 64, ka * 64, kb * 64});
           }
         }
@@ -195,6 +197,7 @@ class DagBuilder {
         if (op.klim == 1) kb = std::min(kb, bj + 1);
         if (op.klim == 2) ka = std::max(ka, bj);
         if (op.klim == 3) kb = std::min(kb, bi + 1);
+        if (op.klim == 4) ka = std::max(ka, bi);
         for (int k = ka; k < kb; ++k) {
           double w = 1.0;
           if ((op.tri_a && k == bi) || (op.tri_b && k == bj)) w = 0.5;
@@ -225,6 +228,8 @@ class DagBuilder {
     return c;
   }
 
+  int top_lo_ = 0, top_hi_ = 0, top_mid_ = -1;
+  DagGate top_right_all_;  // the right half of the top node is final (its X22)
   struct Sub {
     int lo = 0, hi = 0;
     std::vector<DagGate> rowfin;  // [j - lo]: row block j of X is final inside this subtree
@@ -288,6 +293,7 @@ class DagBuilder {
     RowGates rgate(hi);
     for (int i = mid; i < hi; ++i) rgate[i] = fine_ ? srow[i] : sall;
     const Sub right = rec(mid, hi, &rgate);
+    if (lo == top_lo_ && hi == top_hi_) { top_mid_ = mid; top_right_all_ = right.all; }
     // ---- X21 = -X22 * U -> W2[2,1]
     Op x{};
     x.flags = DAGF_ABUF | DAGF_BKM | DAGF_CBUF | DAGF_NEG;  // A = W2 (X22), B = W1 (U, contraction along rows), C = W2
@@ -299,6 +305,193 @@ class DagBuilder {
     for (const Tile& tl : xt) {
       const DagTask tk = make(x, tl, &cu);
       push(tk, {fine_ ? right.rowfin[tl.bi - mid] : right.all, uall, sall}, xrow[tl.bi].cnt, xall.cnt, cu);
+    }
+    out.rowfin.resize(hi - lo);
+    for (int j = lo; j < mid; ++j) out.rowfin[j - lo] = left.rowfin[j - lo];
+    for (int j = mid; j < hi; ++j) out.rowfin[j - lo] = xrow[j];
+    out.all = xall;
+    return out;
+  }
+
+  // K^-1 = X^T X (lower): tile (i, j) = sum over k >= i of X(k, i)^T X(k, j); X = L^-1 lower triangular in W2, zeros above
+  // the diagonal in memory.  A tile needs every row of X from its own block row down: the tiles of the bottom-right quarter
+  // wait for the right half of the top node only (they start while the top node's X21 is still being formed), all others
+  // for the whole inverse factor.  Same per-element accumulation order as the LAUUM launch of gemm_kernel (k ascending from
+  // the tile's first row; rows below it start on zeros).
+  void build_lauum(int nb, const Sub& root) {
+    Op l{};
+    l.flags = DAGF_ABUF | DAGF_BBUF | DAGF_AKM | DAGF_BKM | DAGF_CKINV;  // A = B = W2 (contraction along rows), C = K^-1
+    l.r0 = 0; l.r1 = nb; l.c0 = 0; l.c1 = nb; l.lower = true; l.k0 = 0; l.k1 = nb; l.klim = 4; l.tri_a = true; l.tri_b = true;
+    const double g0 = plan_.gflop;
+    const std::vector<Tile> lt = tiles_of(l, false);
+    plan_.gflop_lauum = plan_.gflop - g0;
+    double cu = 0;
+    for (const Tile& tl : lt) {
+      const DagTask tk = make(l, tl, &cu);
+      const bool quarter = top_mid_ >= 0 && tl.bj >= top_mid_;
+      push(tk, {quarter ? top_right_all_ : root.all}, -1, -1, cu);
+      plan_.n_lauum++;
+    }
+  }
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // Right-looking plan.  The recursion above computes T = A21 X11^T with the explicit inverse of the whole left half, so the
+  // first block row of every T -- depth (half width) x 128, and only ready once the left half's inverse is complete -- sits
+  // on the chain between two diagonal blocks: 1.34 of the 2.39 ms of one evaluation at n = 4096.  Here the factor itself is
+  // formed tile by tile, classically:
+  //   LEAF(k)          X_kk = L_kk^-1 from the updated diagonal tile (W1 -> W2 diagonal block, as before)
+  //   TRSM(i,k)        L(i,k) = A(i,k) X_kk^T                      W1, W2 -> W3           (depth 128)
+  //   UPD(i,j,[k0,k1)) A(i,j) -= L(i,k0..k1) L(j,k0..k1)^T          W3 -> W1, i >= j > k   (one column for the tiles needed
+  //                                                                                       soon, ranges of 4 / 8 / 16 columns far from the chain)
+  // so the chain between two diagonal blocks is TRSM(k+1,k) and UPD(k+1,k+1,k): two 128-deep tiles.  The inverse of the
+  // factor follows the factor by the same divide and conquer as before, off the chain:
+  //   U(N) = L21 X11 (W3, W2 -> W1[2,1]),  X21(N) = -X22 U (W2, W1 -> W2[2,1])
+  // and the K^-1 tiles (build_lauum) follow the inverse.  X = L^-1 ends in W2 exactly as in the recursion (all its consumers
+  // are unchanged); L stays intact in W3.  Arithmetic: mathematically the same factor, but a different order of operations
+  // than the launch path's recursion -- parity with it is 1e-12-close, not bitwise.
+  // Dependencies (every wait for a full count):
+  //   leafc[k] | lc[i][k]: tile L(i,k) written (and, through the chain along the row, every L(i,k') with k' < k)
+  //   lrow[N][i]: row i of L21(N) written
+  //   upd(i,j,s): the s-th update of tile (i,j) applied (a chain per tile: updates run in ascending k)
+  //   Uall[N], Xrow[N][i], Xall[N] as in the recursion
+  struct RlNode { int lo, mid, hi; std::vector<int> lrow; };  // lrow[i - mid]: counter id
+  // How the updates of the tiles of block column j are grouped: a list of column ranges [k0, k1) in ascending order.  Far
+  // from the diagonal chain the ranges are wide (deep, efficient tiles: 16, 8 or 4 columns, aligned), the last columns
+  // before j are applied one by one as soon as each is ready.  A range of G columns is ready when its last column is, and
+  // takes G x 8 us: it has to end early enough not to delay column j (NEAR columns for G = 4, +1 for 8, +3 for 16).
+  static std::vector<std::pair<int, int>> rl_groups(int j, int maxgroup, int near) {
+    std::vector<std::pair<int, int>> out;
+    int a = 0;
+    while (a < j) {
+      int g = 1;
+      for (int cand : {32, 16, 8, 4, 2}) {
+        const int extra = cand == 32 ? 6 : (cand == 16 ? 3 : (cand == 8 ? 1 : 0));
+        if (cand <= maxgroup && a % cand == 0 && a + cand <= j - near - extra) { g = cand; break; }
+      }
+      out.push_back({a, a + g});
+      a += g;
+    }
+    return out;
+  }
+  void build_rl(int nb, bool lauum) {
+    // widest grouped update; tiles within NEAR block columns (and NEAR + 1 block rows) of the current column get 64x64 tasks
+    const int GROUP = rl_group_, NEAR = rl_near_;
+    // node tree of the inverse's recursion (same split points as rec())
+    std::vector<RlNode> nodes;
+    std::vector<std::vector<int>> node_of(nb, std::vector<int>(nb, -1));  // node_of[i][k]: node with k in its left, i in its right half
+    struct Frame { int lo, hi; };
+    std::vector<Frame> stack{{0, nb}};
+    while (!stack.empty()) {
+      const Frame f = stack.back();
+      stack.pop_back();
+      if (f.hi - f.lo < 2) continue;
+      const int mid = dag_split_point(f.lo, f.hi);
+      RlNode nd{f.lo, mid, f.hi, {}};
+      for (int i = mid; i < f.hi; ++i) nd.lrow.push_back(new_counter());
+      const int id = (int)nodes.size();
+      nodes.push_back(nd);
+      for (int i = mid; i < f.hi; ++i)
+        for (int k = f.lo; k < mid; ++k) node_of[i][k] = id;
+      stack.push_back({f.lo, mid});
+      stack.push_back({mid, f.hi});
+    }
+    std::vector<DagGate> leafc(nb);
+    std::vector<std::vector<DagGate>> lc(nb, std::vector<DagGate>(nb)), last_upd(nb, std::vector<DagGate>(nb));
+    std::vector<std::vector<std::pair<int, int>>> groups(nb);
+    for (int j = 0; j < nb; ++j) groups[j] = rl_groups(j, GROUP, NEAR);
+    double cu = 0;
+    auto single_tile = [&](Op op, int i, int j) { op.r0 = i; op.r1 = i + 1; op.c0 = j; op.c1 = j + 1; return op; };
+    for (int k = 0; k < nb; ++k) {
+      // ---- diagonal block k
+      {
+        DagTask t{};
+        t.kind = DAG_LEAF;
+        t.row0 = k;
+        const int c = new_counter();
+        push(t, {last_upd[k][k]}, c, -1, cost_.leaf);
+        plan_.n_leaf++;
+        leafc[k] = DagGate{c, 1};
+      }
+      // ---- L(i,k) = A(i,k) X_kk^T -> W3.  Each also waits for its left neighbour L(i,k-1) (long done in practice): "the
+      // last tile of a column range is written" then implies the whole range, so a grouped update needs two waits, not 2 G.
+      for (int i = k + 1; i < nb; ++i) {
+        Op t{};
+        t.flags = DAGF_BBUF | DAGF_C3;  // A = W1, B = W2 (X_kk), C = W3
+        t.k0 = k; t.k1 = k + 1; t.klim = 1; t.tri_b = true;
+        const std::vector<Tile> tt = tiles_of(single_tile(t, i, k), i - k <= NEAR);
+        const int c = new_counter();
+        lc[i][k] = DagGate{c, (int)tt.size()};
+        const int nd = node_of[i][k];
+        for (const Tile& tl : tt) {
+          const DagTask tk = make(t, tl, &cu);
+          push(tk, {leafc[k], last_upd[i][k], k > 0 ? lc[i][k - 1] : DagGate()}, c, nodes[nd].lrow[i - nodes[nd].mid], cu);
+        }
+      }
+      // ---- updates whose column range ends with column k
+      for (int j = k + 1; j < nb; ++j) {
+        int k0 = -1;
+        for (const auto& gr : groups[j])
+          if (gr.second == k + 1) k0 = gr.first;
+        if (k0 < 0) continue;  // column k is inside a wider range of this block column: applied with the range's last column
+        const bool single = k0 == k;
+        for (int i = j; i < nb; ++i) {
+          Op u{};
+          u.flags = DAGF_A3 | DAGF_B3 | DAGF_NEG | DAGF_ACC;  // A = B = W3 (L), C = W1
+          u.lower = (i == j);
+          u.k0 = k0; u.k1 = k + 1;
+          const std::vector<Tile> ut = tiles_of(single_tile(u, i, j), single && j - k <= NEAR && i - k <= NEAR + 1);
+          const int c = new_counter();
+          for (const Tile& tl : ut) {
+            const DagTask tk = make(u, tl, &cu);
+            push(tk, {lc[i][k], lc[j][k], last_upd[i][j]}, c, -1, cu);
+          }
+          last_upd[i][j] = DagGate{c, (int)ut.size()};
+        }
+      }
+    }
+    // ---- the inverse of the factor, by the recursion's divide and conquer
+    const Sub root = rl_inverse(0, nb, nodes, leafc);
+    if (lauum) build_lauum(nb, root);
+  }
+  Sub rl_inverse(int lo, int hi, const std::vector<RlNode>& nodes, const std::vector<DagGate>& leafc) {
+    Sub out;
+    out.lo = lo; out.hi = hi;
+    if (hi - lo == 1) {
+      out.rowfin.assign(1, leafc[lo]);
+      out.all = leafc[lo];
+      return out;
+    }
+    const int mid = dag_split_point(lo, hi);
+    const RlNode* nd = nullptr;
+    for (const RlNode& cand : nodes)
+      if (cand.lo == lo && cand.hi == hi) nd = &cand;
+    const bool small = std::max(mid - lo, hi - mid) <= small_h_;
+    const Sub left = rl_inverse(lo, mid, nodes, leafc);
+    const Sub right = rl_inverse(mid, hi, nodes, leafc);
+    if (lo == top_lo_ && hi == top_hi_) { top_mid_ = mid; top_right_all_ = right.all; }
+    double cu = 0;
+    // U = L21 X11 -> W1[2,1]   (A = W3, B = W2 with the contraction along rows)
+    Op u{};
+    u.flags = DAGF_A3 | DAGF_BBUF | DAGF_BKM;
+    u.r0 = mid; u.r1 = hi; u.c0 = lo; u.c1 = mid; u.k0 = lo; u.k1 = mid; u.klim = 2; u.tri_b = true;
+    const std::vector<Tile> ut = tiles_of(u, small);
+    const DagGate uall{new_counter(), (int)ut.size()};
+    for (const Tile& tl : ut) {
+      const DagTask tk = make(u, tl, &cu);
+      DagGate lrow{nd->lrow[tl.bi - mid], plan_.totals[nd->lrow[tl.bi - mid]]};
+      push(tk, {lrow, left.all}, uall.cnt, -1, cu);
+    }
+    // X21 = -X22 U -> W2[2,1]
+    Op x{};
+    x.flags = DAGF_ABUF | DAGF_BKM | DAGF_CBUF | DAGF_NEG;
+    x.r0 = mid; x.r1 = hi; x.c0 = lo; x.c1 = mid; x.k0 = mid; x.k1 = hi; x.klim = 3; x.tri_a = true; x.crit = 2;
+    const std::vector<Tile> xt = tiles_of(x, small);
+    RowGates xrow(hi);
+    for (int i = mid; i < hi; ++i) xrow[i] = DagGate{new_counter(), count_row(xt, i)};
+    const DagGate xall{new_counter(), (int)xt.size()};
+    for (const Tile& tl : xt) {
+      const DagTask tk = make(x, tl, &cu);
+      push(tk, {fine_ ? right.rowfin[tl.bi - mid] : right.all, uall}, xrow[tl.bi].cnt, xall.cnt, cu);
     }
     out.rowfin.resize(hi - lo);
     for (int j = lo; j < mid; ++j) out.rowfin[j - lo] = left.rowfin[j - lo];
@@ -380,20 +573,6 @@ class DagBuilder {
       for (int w = 0; w < t.nwait; ++w) blc[t.wcnt[w]] = std::max(blc[t.wcnt[w]], bl[i]);
     }
     plan_.crit_us = *std::max_element(bl.begin(), bl.end());
-    if (nchain_ > 0 && prio_slack_ > 0) {
-      // top levels (earliest start with unlimited workers): emission order is topological, one forward sweep
-      std::vector<double> tl(nt, 0.0), ready_at(nc, 0.0);
-      for (int i = 0; i < nt; ++i) {
-        DagTask& t = plan_.tasks[i];
-        for (int w = 0; w < t.nwait; ++w) tl[i] = std::max(tl[i], ready_at[t.wcnt[w]]);
-        for (int q = 0; q < DAG_MAXSIG; ++q)
-          if (t.sig[q] != DAG_NOSIG) ready_at[t.sig[q]] = std::max(ready_at[t.sig[q]], tl[i] + t.cost * 0.1);
-        if (t.kind != DAG_LEAF && plan_.crit_us - (tl[i] + bl[i]) < prio_slack_) {
-          t.flags |= DAGF_PRIO;
-          plan_.n_prio++;
-        }
-      }
-    }
     if (getenv("HBEGP_DAG_DUMP")) {  // the critical path, task by task (diagnostics)
       int cur = (int)(std::max_element(bl.begin(), bl.end()) - bl.begin());
       double acc_leaf = 0, acc_small = 0, acc_big = 0;
@@ -414,41 +593,37 @@ class DagBuilder {
     }
     std::vector<int> count(nc, 0), missing(nt, 0);
     typedef std::pair<double, int> Pri;  // (bottom level, -index): highest first, earlier emission breaks ties
-    // worker class 0: the (bulk) workgroups; class 1: the chain kernel's, which serve the diagonal blocks and nothing else
-    std::priority_queue<Pri> ready[2];
-    auto cls = [&](int i) { return (nchain_ > 0 && plan_.tasks[i].kind == DAG_LEAF) ? 1 : 0; };
+    std::priority_queue<Pri> ready;
     for (int i = 0; i < nt; ++i) {
       missing[i] = plan_.tasks[i].nwait;
-      if (missing[i] == 0) ready[cls(i)].push({bl[i], -i});
+      if (missing[i] == 0) ready.push({bl[i], -i});
     }
     typedef std::pair<double, int> Ev;  // (finish time, task)
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> running;
     std::vector<DagTask> out;
     out.reserve(nt);
-    int idle[2] = {nwg_, nchain_};
+    int idle = nwg_;
     double now = 0;
     while ((int)out.size() < nt) {
-      for (int k = 0; k < 2; ++k)
-        while (idle[k] > 0 && !ready[k].empty()) {
-          const int i = -ready[k].top().second;
-          ready[k].pop();
-          out.push_back(plan_.tasks[i]);
-          const double scale = (k == 0 && nchain_ > 0 && !(plan_.tasks[i].flags & DAGF_PRIO)) ? bulk_scale_ : 1.0;
-          running.push({now + plan_.tasks[i].cost * 0.1 * scale, i});
-          --idle[k];
-        }
+      while (idle > 0 && !ready.empty()) {
+        const int i = -ready.top().second;
+        ready.pop();
+        out.push_back(plan_.tasks[i]);
+        running.push({now + plan_.tasks[i].cost * 0.1, i});
+        --idle;
+      }
       if (running.empty()) break;  // cannot happen for a sound graph
       const Ev e = running.top();
       running.pop();
       now = e.first;
-      ++idle[cls(e.second)];
+      ++idle;
       const DagTask& t = plan_.tasks[e.second];
       for (int q = 0; q < DAG_MAXSIG; ++q) {
         if (t.sig[q] == DAG_NOSIG) continue;
         const int c = t.sig[q];
         if (++count[c] == plan_.totals[c])
           for (int wtr : waiters[c])
-            if (--missing[wtr] == 0) ready[cls(wtr)].push({bl[wtr], -wtr});
+            if (--missing[wtr] == 0) ready.push({bl[wtr], -wtr});
       }
     }
     while (!running.empty()) { now = running.top().first; running.pop(); }
@@ -480,7 +655,7 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
   struct Cell { int writer = -1; std::vector<int> readers; };
   // buffers 0/1: W1/W2 in 64x64 tiles; 2: w (32-row cells); 3: chunk partials (chunk, 128-column cell); 4: diag(L) (128-row
   // cells); 5: per-block sums.  All share one table of nt64 x nt64 cells (the 1-D ones use column 0).
-  constexpr int NBUF = 6;
+  constexpr int NBUF = 8;  // 6: K^-1 (64x64 tiles), 7: W3 (the factor L of the right-looking plan)
   std::vector<Cell> cells[NBUF];
   for (int b = 0; b < NBUF; ++b) cells[b].resize((size_t)nt64 * nt64);
   std::vector<std::vector<uint64_t>> known(nt);
@@ -546,7 +721,8 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
       for (int b = 0; b < (nblocks_total * 128 + 255) / 256; ++b) cell(5, b, 0, false);
     } else {
       const int ta = t.kind == DAG_GEMM_128x64 ? 128 : 64, tb = 64;
-      const int ab = (t.flags & DAGF_ABUF) ? 1 : 0, bb = (t.flags & DAGF_BBUF) ? 1 : 0, cb = (t.flags & DAGF_CBUF) ? 1 : 0;
+      const int ab = (t.flags & DAGF_A3) ? 7 : ((t.flags & DAGF_ABUF) ? 1 : 0), bb = (t.flags & DAGF_B3) ? 7 : ((t.flags & DAGF_BBUF) ? 1 : 0);
+      const int cb = (t.flags & DAGF_CKINV) ? 6 : ((t.flags & DAGF_C3) ? 7 : ((t.flags & DAGF_CBUF) ? 1 : 0));
       if (t.kend <= t.kbeg) return "empty contraction range";
       if (t.flags & DAGF_AKM) rect(ab, t.kbeg, t.kend, t.row0, t.row0 + ta, false);
       else rect(ab, t.row0, t.row0 + ta, t.kbeg, t.kend, false);
@@ -558,7 +734,7 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     for (const Acc& a : accs) {
       if (a.r >= nt64 || a.c >= nt64 || a.r < 0 || a.c < 0) return "tile outside the matrix";
       Cell& cell = cells[a.buf][(size_t)a.r * nt64 + a.c];
-      if (a.buf >= 2 && !a.write && cell.writer < 0) {
+      if (a.buf >= 2 && a.buf != 6 && !a.write && cell.writer < 0) {
         snprintf(buf, sizeof buf, "task %d reads cell (%d,%d) of buffer %d that no earlier task has written", i, a.r, a.c, a.buf);
         return buf;
       }

@@ -88,11 +88,15 @@ enum : uint16_t {
   DAGF_BKM = 16,
   DAGF_NEG = 32,   // alpha = -1
   DAGF_ACC = 64,   // beta = 1
-  DAGF_PRIO = 128, // the task sits on (or next to) the critical path: its waves raise their issue priority (s_setprio) --
-                   // matters when the workgroup shares its CU with another evaluation's workgroup (split launches)
+  DAGF_CKINV = 128,  // the result goes to the launch's K^-1 buffer (tiles of K^-1 = X^T X behind the recursion); skipped when
+                     // the launch asks for the factorisation only
+  // right-looking plan: the Cholesky factor L itself lives in a third work matrix (W3) until the inverse is complete
+  DAGF_A3 = 256,   // operand A lives in W3 (overrides DAGF_ABUF)
+  DAGF_B3 = 512,
+  DAGF_C3 = 1024,  // the result goes to W3 (overrides DAGF_CBUF)
 };
 constexpr int DAG_MAXWAIT = 4;
-constexpr int DAG_MAXSIG = 2;
+constexpr int DAG_MAXSIG = 3;
 constexpr uint16_t DAG_NOSIG = 0xffff;
 struct DagTask {
   uint16_t kind, flags;
@@ -103,34 +107,25 @@ struct DagTask {
   uint16_t wcnt[DAG_MAXWAIT];  // counters waited for ...
   uint16_t wval[DAG_MAXWAIT];  // ... to reach these values (always the counter's full count)
   uint16_t cost;               // host-side estimate (tenths of a microsecond) used to order the queue
-  uint16_t pad_[2];
+  uint16_t pad_[1];
 };
+static_assert(DAG_MAXSIG == 3, "DagTask::sig has three entries: dword 5 high half, dword 6 low half, dword 6 high half");
 static_assert(sizeof(DagTask) == 48, "DagTask layout");  // dag_kernel decodes it dword by dword: keep the field order
 constexpr int DAG_CTRL_WORDS = 4;     // ctrl[0] queue head, [1] first task that gave up waiting (+1), [2..3] spare; counters follow
-// Split launches (a problem whose evaluation slots run concurrently): the queue is served by TWO kernels that share the
-// dependency counters --
-//   chain server: a persistent launch of workgroups with the whole LDS on CUs reserved for it (one per XCC, CU-masked
-//                 stream), alive while the problem lives; one of its workgroups walks an evaluation's diagonal blocks in
-//                 order (they depend on each other anyway);
-//   bulk kernel:  one launch per evaluation, workgroups with 57 KB of LDS, two per CU, pull the tile tasks.  Two
-//                 evaluations' bulk workgroups share a CU, so the matrix pipe of a CU whose workgroup waits for the chain
-//                 works for another optimiser run.
-// Each queue is a subsequence of one topological order; the server's workgroups are resident before the first evaluation
-// starts and never give their CUs up, and the bulk workgroups of other evaluations always drain: both kernels always have
-// a resident workgroup, so the pair makes progress like the single queue.
-// go word (per slot, own allocation, never cleared): the bulk workgroup that pulls task 0 adds 1 -- the stream-ordered
-// memset of the counters and the kernel-matrix launch are complete by then; the server compares it with the number of
-// chains it has started on the slot.
-enum : int { DAG_MODE_ALL = 0, DAG_MODE_BULK = 1, DAG_MODE_CHAIN = 2, DAG_MODE_FULL = 3 };  // FULL = ALL + the kernel-matrix / reduction tasks
 constexpr int DAG_INFO_TIMEOUT = -2;  // written to EvalOut::info when a wait exceeded its bound (a bug, never a data property)
+// Two instantiations of the task-queue kernel: the factorisation's tasks only (the default), or with the kernel-matrix /
+// reduction tasks as well (HBEGP_DAG_FULL).  With everything inlined into one kernel the diagonal block spilled 60 VGPRs
+// (33.5 us per block instead of 27.4).
+enum : int { DAG_MODE_FACTOR = 0, DAG_MODE_FULL = 1 };
 struct DagLaunch {
-  const DagTask* tasks;  // the queue this launch serves (all tasks, the bulk tasks or the chain tasks)
+  const DagTask* tasks;
   int ntasks;
-  int mode;              // DAG_MODE_*
-  int* go;               // split launches only
+  int mode;  // DAG_MODE_*
   int* ctrl;
   void* W1;
   void* W2;
+  void* W3;         // right-looking plan: the factor L (DAGF_A3 / B3 / C3)
+  void* Kinv;       // target of the DAGF_CKINV tiles (null: skip them)
   int ld;
   void* ldiag;
   int* info;
@@ -144,40 +139,9 @@ struct DagLaunch {
   void* alpha;            // np
   EvalOut* out;
   unsigned long long* trace;  // optional (diagnostics): per task [pulled, inputs ready, computed, published] on the 100 MHz clock, then the CU id
-  int trace_base;             // trace row of this launch's task 0 (split launches: bulk rows first, chain rows behind them)
 };
 template <typename T>
-void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);  // mode ALL: nwg workgroups with the whole LDS; BULK: nwg with
-                                                              // DAG_BULK_LDS_BYTES
-// the chain server's view of the evaluation slots of one problem on one device (device memory)
-constexpr int DAG_MAX_SERVED = 8;
-constexpr unsigned long long DAG_SERVER_IDLE_TICKS = 1000000000ull;  // 10 s of the 100 MHz clock
-struct DagServed {
-  const DagTask* tasks;  // the slot's chain queue
-  int ntasks;
-  int ld;
-  int* ctrl;
-  void* W1;
-  void* W2;
-  void* ldiag;
-  int* info;
-  int* go;
-  unsigned long long* trace;
-  int trace_base;
-  int pad_;
-};
-struct DagBoard {
-  int quit;     // host: != 0 -> the server's workgroups leave once idle
-  int alive;    // server workgroups currently running
-  int nslots;
-  int pad_;
-  int claimed[DAG_MAX_SERVED];  // chains started per slot
-  DagServed slot[DAG_MAX_SERVED];
-};
-template <typename T>
-void launch_chain_server(DagBoard* board, int nwg, hipStream_t s);
-// where do the workgroups land?  out[wg] = XCC id << 16 | HW_ID[15:8] (se, sh, cu).  Used by the CU-mask self-test.
-void launch_whereami(unsigned* out, int nwg, int lds_bytes, hipStream_t s);
+void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);
 
 // ---- launchers (kernels.hip), T in {double, float} ------------------------------------------------------------
 template <typename T>

@@ -145,7 +145,6 @@ static DevPool g_pool;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-
 // theta (log space) -> clamped linear-space parameters (fit.rs:94-96)
 static void theta_to_params(const double* theta, const double* lo, const double* hi, int d, EvalParams* P) {
   auto clampv = [&](double v, int i) {
@@ -161,126 +160,6 @@ static void theta_to_params(const double* theta, const double* lo, const double*
 
 // ---------------------------------------------------------------------------------------------------------------
 // timing support for hbegp_problem_time_eval
-// ---------------------------------------------------------------------------------------------------------------
-// CU reservation for the split task-queue launches (engine.hpp, DAG_MODE_*).  Measured on MI355X in SPX mode (256 CUs =
-// 8 XCCs x 32; tools/cumask_probe2.hip, cumask_probe3.hip): bit i of a hipExtStreamCreateWithCUMask mask is CU i / 8 of
-// XCC i % 8; an XCC whose mask bits are all clear gets ALL its CUs back; the workgroups of a dispatch are dealt to the XCCs
-// round-robin from a start that depends on the hardware queue and on the load.  Hence the smallest reservation that does
-// not depend on placement: CU 0 of EVERY XCC (mask bits 0..7) for the chain server, whose 8 workgroups land one per XCC,
-// and everything else for the evaluation streams.
-// Nothing is taken on trust: the device check launches 8 whole-LDS workgroups on the server stream (they must report 8
-// distinct CUs) and a chip-filling launch on an evaluation stream (it must cover exactly the other 248 CUs); otherwise the
-// engine keeps the one-queue launches.  One problem at a time owns the domain of a device; a second concurrent problem on
-// the same device runs the one-queue form.
-// CU-masked streams are blocking streams (the API has no flag): nothing may touch the null stream or call a
-// device-synchronising function (hipFree, hipMemcpy, ...) while a server is running -- the server only runs inside
-// Problem::SplitSession (around the optimiser runs of a fit, around a timing run, around a single evaluation).
-struct SplitDomain {
-  std::atomic<bool> in_use{false};
-  bool checked = false, ok = false;
-  int dev = 0, nserver = 8, bulk_slots_per_xcc = 0;  // bulk_slots_per_xcc: two-workgroup places per XCC on the evaluation streams
-  hipStream_t server = nullptr, ctl = nullptr;
-  std::vector<hipStream_t> bulk;
-  std::vector<uint32_t> bulk_mask;
-};
-static SplitDomain* split_domain_acquire(int dev, int n_slots) {
-  static std::mutex mu;
-  static std::map<int, std::unique_ptr<SplitDomain>> domains;
-  std::lock_guard<std::mutex> lk(mu);
-  std::unique_ptr<SplitDomain>& dp = domains[dev];
-  if (!dp) dp.reset(new SplitDomain());
-  SplitDomain& D = *dp;
-  if (D.in_use.load()) return nullptr;
-  const bool verbose = env_int("HBEGP_DAG_VERBOSE", 0) != 0;
-  int prev = 0;
-  if (hipGetDevice(&prev) != hipSuccess) return nullptr;
-  if (!D.checked) {
-    D.checked = true;
-    D.dev = dev;
-    const char* why = nullptr;
-    hipDeviceProp_t prop;
-    unsigned* d = nullptr;
-    const int nprobe = 2048, words = 8;
-    if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      why = "device query failed";
-    } else if (prop.multiProcessorCount != 256) {
-      why = "not a 256-CU device (MI355X in SPX mode expected)";
-    } else if (hipMalloc(&d, sizeof(unsigned) * (nprobe + 64)) != hipSuccess) {
-      why = "hipMalloc";
-    }
-    std::vector<uint32_t> sm(words, 0);
-    sm[0] = 0xffu;  // CU 0 of every XCC
-    D.bulk_mask.assign(words, 0xffffffffu);
-    D.bulk_mask[0] = ~0xffu;
-    if (!why && hipExtStreamCreateWithCUMask(&D.server, words, sm.data()) != hipSuccess) why = "hipExtStreamCreateWithCUMask (server)";
-    if (!why && hipStreamCreateWithFlags(&D.ctl, hipStreamNonBlocking) != hipSuccess) why = "hipStreamCreateWithFlags";
-    D.bulk.assign(1, nullptr);
-    if (!why && hipExtStreamCreateWithCUMask(&D.bulk[0], words, D.bulk_mask.data()) != hipSuccess) why = "hipExtStreamCreateWithCUMask (evaluation)";
-    std::vector<unsigned> reserved;
-    for (int round = 0; round < 2 && !why; ++round) {
-      launch_whereami(d + nprobe, D.nserver, 159 * 1024, D.server);
-      std::vector<unsigned> h(D.nserver);
-      if (hipStreamSynchronize(D.server) != hipSuccess || hipMemcpy(h.data(), d + nprobe, sizeof(unsigned) * D.nserver, hipMemcpyDeviceToHost) != hipSuccess) {
-        why = "server probe failed";
-        break;
-      }
-      std::sort(h.begin(), h.end());
-      if (std::unique(h.begin(), h.end()) != h.end()) why = "two server workgroups share a CU";
-      if (round == 0) reserved = h;
-      else if (reserved != h) why = "the server's CUs changed between two launches";
-    }
-    if (!why) {
-      launch_whereami(d, nprobe, 58 * 1024, D.bulk[0]);
-      std::vector<unsigned> h(nprobe);
-      if (hipStreamSynchronize(D.bulk[0]) != hipSuccess || hipMemcpy(h.data(), d, sizeof(unsigned) * nprobe, hipMemcpyDeviceToHost) != hipSuccess) {
-        why = "evaluation-stream probe failed";
-      } else {
-        std::sort(h.begin(), h.end());
-        h.erase(std::unique(h.begin(), h.end()), h.end());
-        for (unsigned v : h)
-          if (std::binary_search(reserved.begin(), reserved.end(), v)) why = "a launch on an evaluation stream ran on a reserved CU";
-        if (!why && (int)h.size() != prop.multiProcessorCount - D.nserver) why = "the evaluation mask does not cover exactly the unreserved CUs";
-      }
-    }
-    if (d) (void)hipFree(d);
-    (void)hipGetLastError();
-    if (why) {
-      if (verbose) fprintf(stderr, "split launches disabled on device %d: %s\n", dev, why);
-      if (D.server) (void)hipStreamDestroy(D.server);
-      if (D.ctl) (void)hipStreamDestroy(D.ctl);
-      for (hipStream_t st : D.bulk) if (st) (void)hipStreamDestroy(st);
-      D.server = D.ctl = nullptr;
-      D.bulk.clear();
-    } else {
-      D.ok = true;
-      D.bulk_slots_per_xcc = 2 * (prop.multiProcessorCount / 8 - 1);
-      if (verbose) {
-        fprintf(stderr, "split launches: %d reserved CUs on device %d:", D.nserver, dev);
-        for (unsigned v : reserved) fprintf(stderr, " x%u.se%u.cu%u", v >> 16, (v >> 5) & 7, v & 15);
-        fprintf(stderr, "\n");
-      }
-    }
-  }
-  if (!D.ok || n_slots > DAG_MAX_SERVED) {
-    (void)hipSetDevice(prev);
-    return nullptr;
-  }
-  bool streams_ok = hipSetDevice(dev) == hipSuccess;
-  while (streams_ok && (int)D.bulk.size() < n_slots) {
-    hipStream_t st = nullptr;
-    streams_ok = hipExtStreamCreateWithCUMask(&st, (uint32_t)D.bulk_mask.size(), D.bulk_mask.data()) == hipSuccess;
-    if (streams_ok) D.bulk.push_back(st);
-  }
-  (void)hipGetLastError();
-  (void)hipSetDevice(prev);
-  if (!streams_ok) return nullptr;
-  D.in_use.store(true);
-  return &D;
-}
-static void split_domain_release(SplitDomain* D) {
-  if (D) D->in_use.store(false);
-}
-
 struct PhaseTimer {
   enum Kind { KMAT = 0, GEMM = 1, LEAF = 2, LAUUM = 3, ALPHA = 4, GRAD = 5, DAG = 6, NKIND = 7 };
   struct Rec {
@@ -416,9 +295,6 @@ struct Slot {
   EvalOut* dOut = nullptr;
   unsigned long long* dag_trace = nullptr;  // HBEGP_DAG_TRACE: per-task time stamps of the last evaluation
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
-  // split launches: the diagonal blocks are run by the problem's chain server
-  int* dag_go = nullptr;     // bumped by each bulk launch; the server compares it with the chains it has started on the slot
-  bool borrowed_streams = false;  // stream belongs to the device's SplitDomain
   EvalParams* hP = nullptr;  // pinned
   EvalOut* hOut = nullptr;   // pinned
   hipGraphExec_t graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [target][want_grad]
@@ -429,6 +305,7 @@ struct Slot {
   std::vector<double> best_theta;
   int last_target = 0;  // buffer written by the most recent evaluation
   int dag_target = 0;   // alpha buffer the task-queue launch writes (its alpha / lml tasks)
+  T* dag_kinv = nullptr;  // K^-1 buffer the task-queue launch writes (its X^T X tiles); null: factorisation only
   int gemm_ord = 0;     // ordinal of the next GEMM launch inside the current evaluation (indexes the static schedules)
 };
 
@@ -453,14 +330,10 @@ struct Problem : ProblemBase {
   // device-scheduled factorisation (dag_kernel.inc.hpp): one plan per problem, the same on every device
   bool dag_ = false;
   bool dag_full_ = false;                   // the kernel-matrix tiles and the alpha / lml reductions are tasks of the queue too
-  std::vector<DagTask*> dag_tasks;          // per device (split launches: the bulk queue)
-  bool split_ = false;                      // chain + bulk launches instead of one (engine.hpp, DAG_MODE_*)
-  std::vector<SplitDomain*> domains_;       // per device: the reserved CUs and the CU-masked streams (owned while the problem lives)
-  std::vector<DagBoard*> boards_;           // per device: what the chain server sees (device memory)
-  std::mutex session_mu_;
-  std::vector<int> session_refs_;           // per device: open sessions (the server runs while > 0)
-  std::vector<DagTask*> dag_chain_tasks;    // per device: the chain queue (diagonal blocks)
-  int dag_nchain_tasks = 0;
+  bool dag_lauum_ = false;                  // the tiles of K^-1 = X^T X are tasks of the queue too (no LAUUM launch)
+  bool dag_rl_ = false;                     // right-looking plan (dag_plan.hpp build_rl): the factor L lives in W3
+  double dag_gflop_lauum = 0;
+  std::vector<DagTask*> dag_tasks;          // per device
   int dag_ntasks = 0, dag_nwg = 0;
   std::vector<DagTask> dag_host_tasks;      // kept for the trace dump
   size_t dag_ctrl_bytes = 0;
@@ -496,22 +369,6 @@ struct Problem : ProblemBase {
     Xd.assign(c->devs.size(), nullptr);
     yd.assign(c->devs.size(), nullptr);
     slots.resize(c->devs.size());
-    // Which form the factorisation takes is decided first: the split launches need CU-masked streams.
-    const int dag_env = env_int("HBEGP_DAG", -1);
-    dag_ = (dag_env < 0 ? (n_slots >= 2 || np / NB > 36) : dag_env != 0) && !adhoc_ && np / NB >= 2;
-    if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
-    dag_full_ = dag_ && env_int("HBEGP_DAG_FULL", 0) != 0;
-    // Split launches: default for problems whose slots evaluate concurrently (a fit).  One evaluation alone gains nothing
-    // from sharing CUs (HBEGP_DAG_SPLIT=1 forces it, 0 switches it off).
-    const int split_env = env_int("HBEGP_DAG_SPLIT", -1);
-    split_ = dag_ && !dag_full_ && !is_f32 && (split_env < 0 ? false : split_env != 0);  // f64 only: the f32 tile task needs 186 VGPRs, two workgroups per CU allow 128
-    domains_.assign(c->devs.size(), nullptr);
-    for (size_t di = 0; di < c->devs.size() && split_; ++di) {
-      domains_[di] = split_domain_acquire(c->devs[di], n_slots);
-      if (!domains_[di]) split_ = false;
-    }
-    if (!split_)
-      for (auto& dptr : domains_) { split_domain_release(dptr); dptr = nullptr; }
     for (size_t di = 0; di < c->devs.size(); ++di) {
       HIPCHECK(hipSetDevice(c->devs[di]));
       HIPCHECK(hipMalloc(&Xd[di], sizeof(T) * (size_t)n * d));
@@ -520,18 +377,9 @@ struct Problem : ProblemBase {
       HIPCHECK(hipMemcpy(Xd[di], X, sizeof(T) * (size_t)n * d, hipMemcpyHostToDevice));
       HIPCHECK(hipMemcpy(yd[di], y, sizeof(T) * n, hipMemcpyHostToDevice));
       slots[di].resize(n_slots);
-      int slot_idx = 0;
       for (auto& s : slots[di]) {
         s.dev = c->devs[di];
-        if (split_) {
-          s.stream = domains_[di]->bulk[slot_idx];         // the domain's streams outlive the problem
-          s.borrowed_streams = true;
-          HIPCHECK(hipMalloc(&s.dag_go, 64));
-          HIPCHECK(hipMemset(s.dag_go, 0, 64));
-        } else {
-          HIPCHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        }
-        ++slot_idx;
+        HIPCHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         bool fresh1 = false, fresh2 = false, fk = false;
         s.W1 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh1));
         s.W2 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh2));
@@ -572,6 +420,12 @@ struct Problem : ProblemBase {
     // evaluation alone, launches vs task queue: n=4096 2.92 vs 2.98 ms, 6144 7.10 vs 5.90, 8192 12.7 vs 10.6, 16384 86.3 vs
     // 72.1); below that a single evaluation stream is a few per cent faster as a chain of launches.
     // HBEGP_DAG=0/1 forces it (read per problem: the parity tests flip it inside one process).
+    const int dag_env = env_int("HBEGP_DAG", -1);
+    // measured (config M data, launches vs task queue): one evaluation alone n=1536: 0.75 / 0.78 ms, 2048: 1.05 / 1.02, 4096: 2.89 / 2.19,
+    // 8192: 12.7 / 9.9; three concurrent optimiser runs (fits/s) n=512: 21.1 / 19.6, 1024: 11.35 / 11.48, 1536: 6.80 / 7.95, 4096: 1.29 / 1.58
+    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", n_slots >= 2 ? 8 : 16);
+    dag_ = (dag_env < 0 ? np / NB >= dag_min_blocks : dag_env != 0) && !adhoc_ && np / NB >= 2;
+    if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
       int cus = 256;
       {
@@ -581,12 +435,6 @@ struct Problem : ProblemBase {
       }
       const int forced = env_int("HBEGP_DAG_WG", 0);
       dag_nwg = forced > 0 ? forced : std::max(1, cus / std::max(1, n_slots));
-      if (split_) {
-        // bulk workgroups: two per CU on the 31 CUs per XCC the server leaves; the launches of all slots together fill them
-        const int per_xcc = domains_[0]->bulk_slots_per_xcc / std::max(1, n_slots);
-        const int forced_b = env_int("HBEGP_BULK_WG", 0);
-        dag_nwg = forced_b > 0 ? forced_b : std::max(8, 8 * per_xcc);
-      }
       // plans depend only on (blocks, stage depth, tiling and ordering knobs): the caller fits one model per generation with
       // slowly growing n, so they are kept (building + simulating the n=4096 queue costs ~15 ms of host time per fit)
       // HBEGP_DAG_FULL=1: kmat and the alpha / lml reductions as tasks of the same queue instead of launches around it (under
@@ -594,54 +442,67 @@ struct Problem : ProblemBase {
       // vs 1.524 fit+predict/s, 2.64 vs 2.55 ms for one evaluation alone -- one 512-thread workgroup per CU gives the fp64
       // exp/sqrt code of the kernel-matrix tiles a quarter of the occupancy the launch has, and the alpha passes become a
       // dependent tail on 85 CUs.  Off by default.
-      const int prio_slack = split_ ? env_int("HBEGP_DAG_PRIO_SLACK", 100) : 0;     // microseconds
-      const int bulk_scale = split_ ? env_int("HBEGP_DAG_BULK_SCALE", 100) : 100;   // per cent: simulated slow-down of a shared CU
-      const std::array<int, 10> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
-                                       env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, split_ ? 1 : 0, prio_slack, bulk_scale};
+      dag_full_ = env_int("HBEGP_DAG_FULL", 0) != 0;
+      // HBEGP_DAG_LAUUM (default 1): the tiles of K^-1 = X^T X follow the recursion in the same queue, as 128x64 tile tasks,
+      // instead of a gemm_kernel launch behind the task-queue launch
+      dag_lauum_ = !dag_full_ && env_int("HBEGP_DAG_LAUUM", 1) != 0;
+      // HBEGP_DAG_RL: right-looking tile Cholesky + divide-and-conquer inverse instead of the recursion that carries the
+      // inverse: two 128-deep tiles between consecutive diagonal blocks instead of products as deep as the node is wide
+      // (critical path of one evaluation at n = 4096: 2.83 -> 2.02 ms, simulated).  Not bitwise equal to the launch path
+      // (another order of operations); the recursion plan stays available (0) and is what the bitwise tests pin.
+      dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", 1) != 0;
+      std::array<int, 11> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
+                                 env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
+                                 env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1)};
       static std::mutex cache_mu;
-      static std::map<std::array<int, 10>, std::shared_ptr<const DagPlan>> cache;
+      static std::map<std::array<int, 11>, std::shared_ptr<const DagPlan>> cache;
       std::shared_ptr<const DagPlan> cached;
-      {
-        std::lock_guard<std::mutex> lk(cache_mu);
-        auto it = cache.find(key);
-        if (it != cache.end()) cached = it->second;
-      }
-      if (!cached) {
-        DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5], split_ ? 1 : 0, (double)prio_slack, bulk_scale * 0.01);
-        cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_));
-        std::lock_guard<std::mutex> lk(cache_mu);
-        if (cache.size() > 64) cache.clear();
-        cache[key] = cached;
+      for (int attempt = 0; attempt < 2 && !cached; ++attempt) {
+        {
+          std::lock_guard<std::mutex> lk(cache_mu);
+          auto it = cache.find(key);
+          if (it != cache.end()) cached = it->second;
+        }
+        if (!cached) {
+          DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5]);
+          builder.set_rl(key[9], key[10]);
+          cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_, dag_lauum_, dag_rl_));
+          std::lock_guard<std::mutex> lk(cache_mu);
+          if (cache.size() > 64) cache.clear();
+          cache[key] = cached;
+        }
+        if (cached->tasks.empty() && dag_rl_) {  // too many counters for 16-bit ids (n > ~12k): the recursion plan needs far fewer
+          dag_rl_ = false;
+          key[8] = 0;
+          key[2] = env_int("HBEGP_DAG_SMALLH", 8);
+          cached.reset();
+        }
       }
       const DagPlan& plan = *cached;
-      if (plan.tasks.empty()) dag_ = split_ = false;  // too many counters for 16-bit ids (n > 32k): launch-per-product path
+      if (plan.tasks.empty()) dag_ = dag_lauum_ = false;  // too many counters for 16-bit ids (n > 32k): launch-per-product path
       if (dag_ && env_int("HBEGP_DAG_VALIDATE", 0)) {
         const std::string why = dag_plan_validate(plan, np / NB);
         if (!why.empty()) throw std::runtime_error("task queue of the factorisation is unsound: " + why);
       }
       if (dag_ && env_int("HBEGP_DAG_VERBOSE", 0))
-        fprintf(stderr, "dag plan: %zu tasks (%zu chain, %d with priority), %zu counters, %d workgroups, critical path %.0f us, simulated %.0f us, %.2f GFLOP\n",
-                plan.tasks.size(), plan.chain.size(), plan.n_prio, plan.totals.size(), dag_nwg, plan.crit_us, plan.sim_us, plan.gflop);
+        fprintf(stderr, "dag plan: %zu tasks (%d K^-1 tiles), %zu counters, %d workgroups, critical path %.0f us, simulated %.0f us, %.2f GFLOP (%.2f in K^-1)\n",
+                plan.tasks.size(), plan.n_lauum, plan.totals.size(), dag_nwg, plan.crit_us, plan.sim_us, plan.gflop, plan.gflop_lauum);
       if (dag_) {
-        const std::vector<DagTask>& queue = split_ ? plan.bulk : plan.tasks;
-        dag_ntasks = (int)queue.size();
-        dag_nchain_tasks = split_ ? (int)plan.chain.size() : 0;
+        dag_ntasks = (int)plan.tasks.size();
         dag_nwg = std::min(dag_nwg, dag_ntasks);
         dag_gflop = plan.gflop;
+        dag_gflop_lauum = plan.gflop_lauum;
         dag_ctrl_bytes = (sizeof(int) * (DAG_CTRL_WORDS + plan.totals.size()) + 15) / 16 * 16;
         dag_tasks.assign(c->devs.size(), nullptr);
-        dag_chain_tasks.assign(c->devs.size(), nullptr);
-        boards_.assign(c->devs.size(), nullptr);
-        session_refs_.assign(c->devs.size(), 0);
         for (size_t di = 0; di < c->devs.size(); ++di) {
           HIPCHECK(hipSetDevice(c->devs[di]));
-          HIPCHECK(hipMalloc(&dag_tasks[di], sizeof(DagTask) * queue.size()));
-          HIPCHECK(hipMemcpy(dag_tasks[di], queue.data(), sizeof(DagTask) * queue.size(), hipMemcpyHostToDevice));
-          if (split_) {
-            HIPCHECK(hipMalloc(&dag_chain_tasks[di], sizeof(DagTask) * plan.chain.size()));
-            HIPCHECK(hipMemcpy(dag_chain_tasks[di], plan.chain.data(), sizeof(DagTask) * plan.chain.size(), hipMemcpyHostToDevice));
-          }
+          HIPCHECK(hipMalloc(&dag_tasks[di], sizeof(DagTask) * plan.tasks.size()));
+          HIPCHECK(hipMemcpy(dag_tasks[di], plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
           for (auto& s : slots[di]) {
+            if (dag_rl_ && !s.W3) {
+              bool f3 = false;
+              s.W3 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &f3));  // the factor L: every tile read has been written
+            }
             HIPCHECK(hipMalloc(&s.dag_ctrl, dag_ctrl_bytes));
             HIPCHECK(hipMemset(s.dag_ctrl, 0, dag_ctrl_bytes));
             if (getenv("HBEGP_DAG_TRACE")) {
@@ -649,21 +510,7 @@ struct Problem : ProblemBase {
               HIPCHECK(hipMemset(s.dag_trace, 0, sizeof(unsigned long long) * 5 * plan.tasks.size()));
             }
           }
-          dag_host_tasks = queue;  // trace rows: this launch's queue, then (split launches) the chain queue
-          if (split_) dag_host_tasks.insert(dag_host_tasks.end(), plan.chain.begin(), plan.chain.end());
-          if (split_) {
-            DagBoard hb{};
-            hb.nslots = n_slots;
-            for (int si = 0; si < n_slots; ++si) {
-              Slot<T>& sl = slots[di][si];
-              DagServed& sv = hb.slot[si];
-              sv.tasks = dag_chain_tasks[di]; sv.ntasks = dag_nchain_tasks; sv.ld = np; sv.ctrl = sl.dag_ctrl;
-              sv.W1 = sl.W1; sv.W2 = sl.W2; sv.ldiag = sl.ldiag; sv.info = &sl.dOut->info; sv.go = sl.dag_go;
-              sv.trace = sl.dag_trace; sv.trace_base = dag_ntasks;
-            }
-            HIPCHECK(hipMalloc(&boards_[di], sizeof(DagBoard)));
-            HIPCHECK(hipMemcpy(boards_[di], &hb, sizeof(DagBoard), hipMemcpyHostToDevice));
-          }
+          dag_host_tasks = plan.tasks;
         }
       }
     }
@@ -691,23 +538,18 @@ struct Problem : ProblemBase {
         g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb); g_pool.put(s.dev, s.W3, nnb);
         for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
         (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
-        (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace); (void)hipFree(s.dag_go);
+        (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace);
         (void)hipHostFree(s.hP); (void)hipHostFree(s.hOut);
-        if (s.stream && !s.borrowed_streams) (void)hipStreamDestroy(s.stream);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
       }
       (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
       if (di < dag_tasks.size()) (void)hipFree(dag_tasks[di]);
-      if (di < dag_chain_tasks.size()) (void)hipFree(dag_chain_tasks[di]);
-      if (di < boards_.size()) (void)hipFree(boards_[di]);
       if (di < scheds.size())
         for (auto& sc : scheds[di]) { (void)hipFree(sc.d_off); (void)hipFree(sc.d_items); }
     }
-    for (auto& dptr : domains_) { split_domain_release(dptr); dptr = nullptr; }
     slots.clear();
     scheds.clear();
     dag_tasks.clear();
-    dag_chain_tasks.clear();
-    boards_.clear();
     Xd.clear();
     yd.clear();
   }
@@ -840,67 +682,14 @@ struct Problem : ProblemBase {
     }
   }
 
-  DagLaunch dag_launch_args(Slot<T>& s, size_t di) {
-    DagLaunch g{};
-    g.tasks = dag_tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
-    g.mode = split_ ? DAG_MODE_BULK : (dag_full_ ? DAG_MODE_FULL : DAG_MODE_ALL);
-    g.go = s.dag_go;
-    g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
-    g.X = Xd[di]; g.y = yd[di]; g.P = s.dP; g.n = n; g.d = d; g.nu2 = nu2;
-    g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
-    g.trace = s.dag_trace; g.trace_base = 0;
-    return g;
-  }
-  // The chain server runs while at least one session is open on the device.  No null-stream work, no hipFree, no
-  // hipDeviceSynchronize inside a session (the server's stream is a blocking stream that never drains until quit).
-  void session_enter(size_t di) {
-    if (!split_) return;
-    std::lock_guard<std::mutex> lk(session_mu_);
-    if (session_refs_[di]++ > 0) return;
-    SplitDomain& D = *domains_[di];
-    HIPCHECK(hipSetDevice(D.dev));
-    // quit = alive = 0; claimed[] keeps counting with go[] across sessions (every chain a slot asked for has been walked)
-    HIPCHECK(hipMemsetAsync(boards_[di], 0, 2 * sizeof(int), D.ctl));
-    HIPCHECK(hipStreamSynchronize(D.ctl));
-    launch_chain_server<T>(boards_[di], D.nserver, D.server);
-    CHECK_LAUNCHES();
-  }
-  void session_leave(size_t di) {
-    if (!split_) return;
-    std::lock_guard<std::mutex> lk(session_mu_);
-    if (--session_refs_[di] > 0) return;
-    SplitDomain& D = *domains_[di];
-    (void)hipSetDevice(D.dev);
-    (void)hipMemsetAsync(boards_[di], 1, sizeof(int), D.ctl);  // quit != 0
-    (void)hipStreamSynchronize(D.ctl);
-    (void)hipStreamSynchronize(D.server);
-  }
-  struct SplitSession {
-    Problem* p;
-    std::vector<size_t> devs;
-    explicit SplitSession(Problem* prob) : p(prob) {}
-    SplitSession(Problem* prob, size_t di) : p(prob) { enter(di); }
-    void enter(size_t di) { p->session_enter(di); devs.push_back(di); }
-    void enter_all() { for (size_t di = 0; di < p->slots.size(); ++di) enter(di); }
-    ~SplitSession() { for (size_t di : devs) p->session_leave(di); }
-  };
   // Diagnostics of a wait that exceeded its bound (a scheduling bug, never a data property): which task gave up, and
   // where its counters stood.
-  void dag_report_timeout(Slot<T>& s, size_t di) {
+  void dag_report_timeout(Slot<T>& s) {
     if (!s.dag_ctrl) return;
     std::vector<int> ctrl(dag_ctrl_bytes / sizeof(int));
-    hipStream_t st = split_ ? domains_[di]->ctl : s.stream;
-    if (hipMemcpyAsync(ctrl.data(), s.dag_ctrl, dag_ctrl_bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return;
-    int go = -1;
-    DagBoard hb{};
-    if (split_) {
-      (void)hipMemcpyAsync(&go, s.dag_go, sizeof(int), hipMemcpyDeviceToHost, st);
-      (void)hipMemcpyAsync(&hb, boards_[di], sizeof(DagBoard), hipMemcpyDeviceToHost, st);
-      (void)hipStreamSynchronize(st);
-    }
+    if (hipMemcpy(ctrl.data(), s.dag_ctrl, dag_ctrl_bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
     const int row = ctrl[1] - 1;
-    fprintf(stderr, "task queue timeout: queue head %d of %d (+%d chain), first task that gave up: row %d; go %d, server: alive %d quit %d claimed %d %d %d\n",
-            ctrl[0], dag_ntasks, dag_nchain_tasks, row, go, hb.alive, hb.quit, hb.claimed[0], hb.claimed[1], hb.claimed[2]);
+    fprintf(stderr, "task queue timeout: queue head %d of %d, first task that gave up: %d\n", ctrl[0], dag_ntasks, row);
     if (row >= 0 && row < (int)dag_host_tasks.size()) {
       const DagTask& t = dag_host_tasks[row];
       fprintf(stderr, "  kind %d flags %x row0 %d col0 %d k [%d, %d) waits:", t.kind, t.flags, t.row0, t.col0, t.kbeg, t.kend);
@@ -908,11 +697,6 @@ struct Problem : ProblemBase {
       fprintf(stderr, "\n");
     }
     (void)hipGetLastError();
-  }
-  // Replay a captured evaluation.
-  void replay(Slot<T>& s, size_t di, hipGraphExec_t ge) {
-    (void)di;
-    HIPCHECK(hipGraphLaunch(ge, s.stream));
   }
 
   // Top of the factorisation.  Above `big` (in 128-blocks) the binary recursion would issue a chain of mid-size,
@@ -924,11 +708,19 @@ struct Problem : ProblemBase {
       // the whole recursion in ONE persistent launch: workgroups pull diagonal-block and tile tasks from an ordered queue
       if (dry_) return;
       HIPCHECK(hipMemsetAsync(s.dag_ctrl, 0, dag_ctrl_bytes, s.stream));
-      DagLaunch g = dag_launch_args(s, di);
-      if (tm) tm->begin(PhaseTimer::DAG, 0, dag_gflop);
+      DagLaunch g{};
+      g.tasks = dag_tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
+      g.mode = dag_full_ ? DAG_MODE_FULL : DAG_MODE_FACTOR;
+      g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
+      g.W3 = s.W3;
+      g.Kinv = dag_lauum_ ? s.dag_kinv : nullptr;
+      g.X = Xd[di]; g.y = yd[di]; g.P = s.dP; g.n = n; g.d = d; g.nu2 = nu2;
+      g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
+      g.trace = s.dag_trace;
+      if (tm) tm->begin(PhaseTimer::DAG, 0, g.Kinv ? dag_gflop : dag_gflop - dag_gflop_lauum);
       launch_dag<T>(g, dag_nwg, s.stream);
       if (tm) tm->end();
-      return;  // split launches: the chain server (SplitSession) runs the diagonal blocks beside this launch
+      return;
     }
     static const int big_env = env_int("HBEGP_NBIG", 1 << 20);  // measured at n=4096: 8 -> 3.55 ms, 4 -> 3.56, off (binary recursion only) -> 3.43
     const int big = std::max(1, big_env);
@@ -1011,14 +803,15 @@ struct Problem : ProblemBase {
       }
     }
     s.dag_target = target;
+    s.dag_kinv = s.Kinv[target];
     chol_inv(s, di, nb, tm);
     if (!dry_ && !in_queue) {
       if (tm) tm->begin(PhaseTimer::ALPHA);
       launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);
       if (tm) tm->end();
     }
-    {
-      // K^-1 = X^T X (lower)  [LAUUM]
+    if (!(dag_ && dag_lauum_ && !adhoc_)) {
+      // K^-1 = X^T X (lower)  [LAUUM]   (task-queue path: tiles of the same queue, dag_plan.hpp build_lauum)
       GemmLaunch g{};
       g.nops = 1;
       GemmOp& op = g.op[0];
@@ -1044,10 +837,10 @@ struct Problem : ProblemBase {
   int factor_only(size_t di, int si) {
     Slot<T>& s = slots[di][si];
     HIPCHECK(hipSetDevice(s.dev));
-    SplitSession session(this, di);
     s.gemm_ord = 0;
     HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
     launch_reset_out(s.dOut, s.stream);
+    s.dag_kinv = nullptr;  // the captured K^-1 stays as it is
     if (dag_ && dag_full_ && !adhoc_) {
       // the queue also carries the alpha / lml tasks: let them write the alpha buffer that does NOT hold the captured best
       s.dag_target = s.best_idx < 0 ? 1 - s.last_target : 1 - s.best_idx;
@@ -1059,7 +852,7 @@ struct Problem : ProblemBase {
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
     HIPCHECK(hipStreamSynchronize(s.stream));
     if (s.hOut->info < 0) {
-      dag_report_timeout(s, di);
+      dag_report_timeout(s);
       throw HipError{hipErrorLaunchTimeOut, "factorisation task queue: a dependency wait exceeded its bound", __LINE__};
     }
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
@@ -1137,38 +930,35 @@ struct Problem : ProblemBase {
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
   }
 
-  // The captured evaluation of a slot (captured on first use; nothing executes during a capture).
-  hipGraphExec_t ensure_graph(Slot<T>& s, size_t di, int target, bool want_grad) {
-    hipGraphExec_t& ge = s.graph[target][want_grad ? 1 : 0];
-    if (ge) return ge;
-    HIPCHECK(hipSetDevice(s.dev));
-    hipGraph_t gr = nullptr;
-    HIPCHECK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
-    try {
-      enqueue_eval(s, di, target, want_grad, nullptr);
-    } catch (...) {
-      (void)hipStreamEndCapture(s.stream, &gr);
-      throw;
-    }
-    HIPCHECK(hipStreamEndCapture(s.stream, &gr));
-    HIPCHECK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
-    HIPCHECK(hipGraphDestroy(gr));
-    return ge;
-  }
   // Run one evaluation on (device index di, slot si) into ping-pong buffer `target`; blocks until the result is on the host.
   int run_eval(size_t di, int si, int target, bool want_grad, bool use_graph, double* lml, double* grad) {
     Slot<T>& s = slots[di][si];
     HIPCHECK(hipSetDevice(s.dev));
     static const bool graphs_on = env_int("HBEGP_NO_GRAPH", 0) == 0;
-    hipGraphExec_t ge = (use_graph && graphs_on) ? ensure_graph(s, di, target, want_grad) : nullptr;
-    SplitSession session(this, di);  // the chain server runs while the evaluation does (a fit holds its own session open)
-    if (ge) replay(s, di, ge);
-    else enqueue_eval(s, di, target, want_grad, nullptr);
+    if (use_graph && graphs_on) {
+      hipGraphExec_t& ge = s.graph[target][want_grad ? 1 : 0];
+      if (!ge) {
+        hipGraph_t gr = nullptr;
+        HIPCHECK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
+        try {
+          enqueue_eval(s, di, target, want_grad, nullptr);
+        } catch (...) {
+          (void)hipStreamEndCapture(s.stream, &gr);
+          throw;
+        }
+        HIPCHECK(hipStreamEndCapture(s.stream, &gr));
+        HIPCHECK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        HIPCHECK(hipGraphDestroy(gr));
+      }
+      HIPCHECK(hipGraphLaunch(ge, s.stream));
+    } else {
+      enqueue_eval(s, di, target, want_grad, nullptr);
+    }
     HIPCHECK(hipStreamSynchronize(s.stream));
     s.last_target = target;
     const int p = d + 2;
     if (s.hOut->info < 0) {
-      dag_report_timeout(s, di);
+      dag_report_timeout(s);
       throw HipError{hipErrorLaunchTimeOut, "factorisation task queue: a dependency wait exceeded its bound", __LINE__};
     }
     if (s.hOut->info != 0) {
@@ -1205,10 +995,9 @@ struct Problem : ProblemBase {
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
-    std::unique_ptr<SplitSession> session(new SplitSession(this, (size_t)dev));
     HIPCHECK(hipEventRecord(e0, s.stream));
     for (int r = 0; r < reps; ++r) {
-      if (s.graph[0][1]) replay(s, (size_t)dev, s.graph[0][1]);
+      if (s.graph[0][1]) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
       else enqueue_eval(s, (size_t)dev, 0, true, nullptr);  // HBEGP_NO_GRAPH=1
     }
     HIPCHECK(hipEventRecord(e1, s.stream));
@@ -1265,14 +1054,12 @@ struct Problem : ProblemBase {
     (void)hipEventDestroy(e1);
     if (s.dag_trace && getenv("HBEGP_DAG_TRACE")) {
       // one more graph replay on a quiet device, then dump: idx kind row col depth nwait | pulled ready computed published (ticks of 10 ns) | xcc hwid
-      if (s.graph[0][1]) replay(s, (size_t)dev, s.graph[0][1]);
+      if (s.graph[0][1]) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
       HIPCHECK(hipStreamSynchronize(s.stream));
-      session.reset();  // the copy below goes through the null stream
-      const int dag_rows = (int)dag_host_tasks.size();
-      std::vector<unsigned long long> tr((size_t)5 * dag_rows);
+      std::vector<unsigned long long> tr((size_t)5 * dag_ntasks);
       HIPCHECK(hipMemcpy(tr.data(), s.dag_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(getenv("HBEGP_DAG_TRACE"), "w")) {
-        for (int i = 0; i < dag_rows; ++i) {
+        for (int i = 0; i < dag_ntasks; ++i) {
           const DagTask& t = dag_host_tasks[i];
           fprintf(f, "%d %d %d %d %d %d %llu %llu %llu %llu %llu %llu\n", i, t.kind, t.row0, t.col0, t.kend - t.kbeg, t.nwait, tr[5 * i], tr[5 * i + 1],
                   tr[5 * i + 2], tr[5 * i + 3], tr[5 * i + 4] >> 32, tr[5 * i + 4] & 0xffffffffull);
@@ -1280,7 +1067,6 @@ struct Problem : ProblemBase {
         fclose(f);
       }
     }
-    session.reset();
     return HBEGP_OK;
   }
 
@@ -1296,8 +1082,6 @@ struct Problem : ProblemBase {
     // pass 0: warm-up (graph instantiation), pass 1: graph replay, pass 2: eager with events
     std::vector<double> acc(12, 0.0);
     std::mutex acc_mu;
-    for (int si = 0; si < ns; ++si) ensure_graph(slots[di][si], di, 0, true);
-    SplitSession session(this, di);
     for (int pass = 0; pass < 3; ++pass) {
       std::atomic<int> arrived{0};
       std::vector<double> wall(ns, 0.0);
@@ -1623,27 +1407,17 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
     }
   };
 
-  {
-    // split launches: capture the evaluations first (nothing executes), then keep the chain servers running while the
-    // optimiser runs do; they are gone again before anything below touches the null stream
-    if (prob.split_)
-      for (int di = 0; di < ndev; ++di)
-        for (auto& s : prob.slots[di])
-          for (int target = 0; target < 2; ++target) prob.ensure_graph(s, (size_t)di, target, true);
-    typename Problem<T>::SplitSession session(&prob);
-    session.enter_all();
-    std::vector<std::thread> threads;
-    try {
-      for (int di = 0; di < ndev; ++di)
-        for (int si = 0; si < std::min(runs_on[di], max_conc); ++si) threads.emplace_back(worker, di, si);
-    } catch (...) {
-      // thread creation failed part-way (std::system_error): the workers already started own device state -- let them
-      // finish before the error leaves this frame (destroying a joinable std::thread terminates the process)
-      for (auto& t : threads) t.join();
-      throw;
-    }
+  std::vector<std::thread> threads;
+  try {
+    for (int di = 0; di < ndev; ++di)
+      for (int si = 0; si < std::min(runs_on[di], max_conc); ++si) threads.emplace_back(worker, di, si);
+  } catch (...) {
+    // thread creation failed part-way (std::system_error): the workers already started own device state -- let them
+    // finish before the error leaves this frame (destroying a joinable std::thread terminates the process)
     for (auto& t : threads) t.join();
+    throw;
   }
+  for (auto& t : threads) t.join();
   // the workers append to the trace as their evaluations complete; hand it back in (run, eval) order
   if (opt.trace_cap > 0 && trace_n > 1 && opt.trace_run) {
     std::vector<int> order(trace_n);
@@ -2077,7 +1851,9 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0 || nwg < 0) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
   DagBuilder builder(bk, small_h, nwg, (fine & 1) != 0);
-  DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0);  // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too
+  // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too; bit 2: the K^-1 = X^T X tiles behind the recursion;
+  // bit 3: the right-looking plan
+  DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0, (fine & 4) != 0, (fine & 8) != 0);
   // fault injection for the validator's own test: HBEGP_DAG_TEST_FAULT = "drop:<i>" (task i loses its first wait) or
   // "move:<i>:<j>" (task i is moved to queue position j)
   if (const char* fault = getenv("HBEGP_DAG_TEST_FAULT")) {

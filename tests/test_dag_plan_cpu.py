@@ -41,6 +41,21 @@ def test_flops_match_potrf_plus_trtri():
     assert rc == 0 and info["gflop"] == pytest.approx(45.77, abs=0.02)
 
 
+@pytest.mark.parametrize("nb", [1, 2, 3, 5, 8, 11, 16, 24, 32, 33, 64])
+def test_plans_with_the_inverse_tiles_are_sound(nb):
+    # fine bit 2: K^-1 = X^T X as tile tasks behind the recursion (the default form of an evaluation)
+    for bk in (16, 32):
+        for small_h, nwg in [(8, 85), (2, 256), (8, 0), (0, 3)]:
+            rc, info = plan(nb, bk, small_h, nwg, fine=1 | 4)
+            assert rc == 0, (nb, bk, small_h, nwg, info["err"])
+
+
+def test_flops_with_the_inverse_tiles_are_potrf_plus_potri():
+    # n^3 = 68.7 GFLOP at n = 4096, of which lauum 22.95 (as Problem::op_gflop counts the launch it replaces)
+    rc, info = plan(32, fine=1 | 4)
+    assert rc == 0 and info["gflop"] == pytest.approx(45.77 + 22.95, abs=0.03)
+
+
 def test_look_ahead_shortens_the_simulated_schedule():
     _, fine = plan(32, nwg=85, fine=1)
     _, coarse = plan(32, nwg=85, fine=0)

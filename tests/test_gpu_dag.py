@@ -1,6 +1,10 @@
 """GPU: the device-scheduled factorisation (one persistent task-queue launch, csrc/dag_kernel.inc.hpp) against the
-launch-per-product path and the oracle.  Per output element both paths run the same sequence of MFMA accumulations, so
-lml, gradient, alpha, K^-1 and diag(L) must be bitwise equal; the oracle comparison pins both to lml.rs:29-79."""
+launch-per-product path and the oracle.
+  * recursion plan (HBEGP_DAG_RL=0): per output element the same sequence of MFMA accumulations as the launch path, so lml,
+    gradient, alpha, K^-1 and diag(L) must be BITWISE equal -- with the K^-1 = X^T X tiles inside the queue or as a launch;
+  * right-looking plan (the default): the same factor by another order of operations -- equal to the launch path to 1e-11
+    of the largest entry, bitwise reproducible for any number of workgroups and across evaluation slots;
+  * the oracle comparison pins everything to lml.rs:29-79."""
 import math
 
 import numpy as np
@@ -35,30 +39,66 @@ def test_task_queue_is_bitwise_equal_to_launch_path(n, cfg, dtype, monkeypatch):
         theta[0] = theta[1] + math.log(0.5)
         monkeypatch.setenv("HBEGP_F32_REFINE", "0")  # the refined f32 panel solve exists as launches only: compare the plain recursion
     ref = _eval_all(X, y, theta, monkeypatch, "0")
-    for wg, small_h in [(0, 8), (3, 2), (40, 0)]:  # any number of workgroups must give the same bits (and terminate)
-        got = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_WG=wg, HBEGP_DAG_SMALLH=small_h, HBEGP_DAG_VALIDATE=1)
+    # any number of workgroups must give the same bits (and terminate); K^-1 tiles in the queue (default) or as a launch
+    for wg, small_h, lauum in [(0, 8, 1), (3, 2, 1), (40, 0, 0)]:
+        got = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_RL=0, HBEGP_DAG_WG=wg, HBEGP_DAG_SMALLH=small_h, HBEGP_DAG_LAUUM=lauum,
+                        HBEGP_DAG_VALIDATE=1)
         for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(ref, got):
             assert r0 is not None and r1 is not None
             assert r0[0] == r1[0] and np.array_equal(r0[1], r1[1])
             assert np.array_equal(a0, a1) and np.array_equal(k0, k1) and np.array_equal(l0, l1)
 
 
-def test_task_queue_matches_oracle(monkeypatch):
+def _close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.isfinite(b))) and float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(a).max()))
+
+
+@pytest.mark.parametrize("n,cfg,dtype", [(200, "C2", np.float64), (300, "M", np.float64), (1100, "C3", np.float64), (1409, "C2", np.float64),
+                                          (2048, "M", np.float64), (2300, "M", np.float64), (600, "C5", np.float32), (1536, "C5", np.float32)])
+def test_right_looking_plan_agrees_with_launch_path_and_is_reproducible(n, cfg, dtype, monkeypatch):
+    w = synth.make_workload(cfg, n=n)
+    X, y, theta = w["X"].astype(dtype), w["y"].astype(dtype), w["theta"].copy()
+    tol = 1e-11
+    if dtype == np.float32:
+        theta[0] = theta[1] + math.log(0.5)
+        monkeypatch.setenv("HBEGP_F32_REFINE", "0")
+        tol = 2e-5  # two f32 orders of operations
+    ref = _eval_all(X, y, theta, monkeypatch, "0")
+    first = None
+    for wg, near, group in [(0, 1, 32), (3, 1, 32), (40, 1, 32), (0, 2, 4)]:
+        got = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_RL=1, HBEGP_DAG_WG=wg, HBEGP_DAG_RL_NEAR=near, HBEGP_DAG_RL_GROUP=group,
+                        HBEGP_DAG_VALIDATE=1)
+        for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(ref, got):
+            assert r0 is not None and r1 is not None
+            assert _close(r0[0], r1[0], tol) and _close(r0[1], r1[1], tol)
+            assert _close(a0, a1, tol) and _close(np.tril(k0), np.tril(k1), tol) and _close(l0, l1, tol)
+        if (near, group) == (1, 32):  # same plan, another number of workgroups: same bits
+            if first is None:
+                first = got
+            for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(first, got):
+                assert r0[0] == r1[0] and np.array_equal(r0[1], r1[1]) and np.array_equal(a0, a1) and np.array_equal(k0, k1)
+
+
+@pytest.mark.parametrize("rl", [0, 1])
+def test_task_queue_matches_oracle(rl, monkeypatch):
     w = synth.make_workload("C2", n=700)
     X, y, theta = w["X"], w["y"], w["theta"]
-    (r, (alpha, kinv, ldiag)), = _eval_all(X, y, theta, monkeypatch, "1", reps=1)
+    (r, (alpha, kinv, ldiag)), = _eval_all(X, y, theta, monkeypatch, "1", reps=1, HBEGP_DAG_RL=rl)
     s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
     ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
     assert abs(r[0] - ref["lml"]) <= 1e-8 * max(1.0, abs(ref["lml"]))
     np.testing.assert_allclose(r[1], ref["grad"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["grad"]).max()))
     np.testing.assert_allclose(alpha, ref["alpha"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["alpha"]).max()))
-    np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["k_inv"]).max()))
+    np.testing.assert_allclose(np.tril(kinv), np.tril(ref["k_inv"]), rtol=0, atol=1e-8 * max(1.0, np.abs(ref["k_inv"]).max()))
 
 
-def test_task_queue_drains_when_not_positive_definite(monkeypatch):
+@pytest.mark.parametrize("rl", [0, 1])
+def test_task_queue_drains_when_not_positive_definite(rl, monkeypatch):
     # lml.rs:47-50: the failing diagonal block flags the evaluation; every later task skips its work but still bumps its
     # counters, so the queue drains at once and the slot is usable again
     monkeypatch.setenv("HBEGP_DAG", "1")
+    monkeypatch.setenv("HBEGP_DAG_RL", str(rl))
     rng = np.random.default_rng(5)
     X = rng.random((400, 3))
     X[300] = X[10]  # duplicate rows + vanishing noise: block 2 fails, blocks 0-1 succeed
@@ -73,7 +113,7 @@ def test_concurrent_slots_share_the_chip_and_agree(monkeypatch):
     # three slots evaluated from three host threads (what a fit does): each slot's launch holds a third of the CUs
     import threading
 
-    monkeypatch.delenv("HBEGP_DAG", raising=False)  # default: task queue on for problems with concurrent slots
+    monkeypatch.setenv("HBEGP_DAG", "1")  # the single-slot problem below would take the launch path at this size
     w = synth.make_workload("M", n=1500)
     X, y, theta = w["X"], w["y"], w["theta"]
     prob = gpr.Problem(X, y, n_slots=3)
@@ -95,12 +135,15 @@ def test_concurrent_slots_share_the_chip_and_agree(monkeypatch):
             assert res[slot][rep][0] == single[k][0] and np.array_equal(res[slot][rep][1], single[k][1])
 
 
-def test_concurrent_soak_against_launch_path(monkeypatch):
+@pytest.mark.parametrize("rl", [0, 1])
+def test_concurrent_soak_against_launch_path(rl, monkeypatch):
     # tools/dag_soak.py in small: 3 slots x 40 rounds of different theta at once (odd block count), every result bit for bit
-    # what the launch path returns on a quiet device -- a stale operand anywhere would show
+    # (recursion plan) / to 1e-11 (right-looking plan) what the launch path returns on a quiet device -- a stale operand
+    # anywhere would show
     import threading
 
-    monkeypatch.delenv("HBEGP_DAG", raising=False)
+    monkeypatch.setenv("HBEGP_DAG", "1")
+    monkeypatch.setenv("HBEGP_DAG_RL", str(rl))
     w = synth.make_workload("M", n=1300)
     X, y = w["X"], w["y"]
     rng = np.random.default_rng(7)
@@ -122,5 +165,7 @@ def test_concurrent_soak_against_launch_path(monkeypatch):
     for i, th in enumerate(thetas):
         r = ref.lml_with_gradient(th)
         assert (r is None) == (got[i] is None)
-        if r is not None:
+        if r is not None and rl == 0:
             assert r[0] == got[i][0] and np.array_equal(r[1], got[i][1]), i
+        elif r is not None:
+            assert _close(r[0], got[i][0], 1e-11) and _close(r[1], got[i][1], 1e-11), i

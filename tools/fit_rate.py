@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Quick rate probe for configuration sweeps: fixed-work fits of config M (no predict, no roofline extras).
-Usage: fit_rate.py [fits]   -> prints fits/s, ms per fit, amortised ms per evaluation; env switches apply."""
+Usage: fit_rate.py [fits [n]]   -> prints fits/s, ms per fit, amortised ms per evaluation; env switches apply."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hbetune_rs_amd import gpr, synth
 
 nfit = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-w = synth.make_workload("M")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else None
+w = synth.make_workload("M", n=n)
 X, y = w["X"], w["y"]
 starts = synth.restart_points("M", w["lo"], w["hi"], 2)
 ctx = gpr.Context(device_ids=[0])
