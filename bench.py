@@ -123,7 +123,10 @@ def kernel_table(tc, n, d, dtype_bytes=8):
                          "share_of_round": ms / rnd})
 
     wg = int(tc["task_queue_workgroups"])
-    mfma("dag_kernel (Cholesky + inverse factor: diagonal blocks + tile tasks)" if wg else "leaf_kernel + gemm_kernel launches (Cholesky + inverse factor)",
+    in_queue = wg and tc["lauum_ms"] <= 0  # the K^-1 = X^T X tiles are tasks of the same launch (the default)
+    mfma(("dag_kernel (Cholesky + inverse factor + K^-1: diagonal blocks + tile tasks)" if in_queue else
+          "dag_kernel (Cholesky + inverse factor: diagonal blocks + tile tasks)") if wg else
+         "leaf_kernel + gemm_kernel launches (Cholesky + inverse factor)",
          tc["factor_ms"], tc["factor_gflop"], tc["factor_launches"])
     mfma("gemm_kernel (LAUUM: K^-1 = X^T X)", tc["lauum_ms"], tc["lauum_gflop"], 1)
     tri = n * n / 2 * dtype_bytes * 1e-6
