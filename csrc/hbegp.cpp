@@ -434,7 +434,13 @@ struct Problem : ProblemBase {
         cus = std::max(1, prop.multiProcessorCount);
       }
       const int forced = env_int("HBEGP_DAG_WG", 0);
-      dag_nwg = forced > 0 ? forced : std::max(1, cus / std::max(1, n_slots));
+      // Concurrent slots: each launch gets a little more than its share of the CUs (a multiple of 8: the dispatcher deals
+      // workgroups round-robin to the 8 XCCs).  The surplus workgroups of a launch start on the CUs another slot's launch has
+      // just given back (that slot is in its short kmat / alpha / gradient launches) and leave when their own queue is empty.
+      // Measured, 3 slots, n=4096, fit+predict/s: 80 -> 1.58, 85 -> 1.62, 88 -> 1.64, 96 -> 1.68, 104 -> 1.64, 112 -> 1.68,
+      // 120 -> 1.54, 128 -> 1.60, 170 -> 1.43, 256 -> 1.14.
+      const int share = n_slots <= 1 ? cus : std::max(8, (cus * env_int("HBEGP_DAG_OVERSUB", 112) / 100 / n_slots + 4) / 8 * 8);  // 3 slots: 96
+      dag_nwg = forced > 0 ? forced : std::max(1, std::min(cus, share));
       // plans depend only on (blocks, stage depth, tiling and ordering knobs): the caller fits one model per generation with
       // slowly growing n, so they are kept (building + simulating the n=4096 queue costs ~15 ms of host time per fit)
       // HBEGP_DAG_FULL=1: kmat and the alpha / lml reductions as tasks of the same queue instead of launches around it (under
@@ -451,7 +457,7 @@ struct Problem : ProblemBase {
       // (critical path of one evaluation at n = 4096: 2.83 -> 2.02 ms, simulated).  Not bitwise equal to the launch path
       // (another order of operations); the recursion plan stays available (0) and is what the bitwise tests pin.
       dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", 1) != 0;
-      std::array<int, 11> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? dag_nwg : 0,
+      std::array<int, 11> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", dag_nwg) : 0,
                                  env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                  env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1)};
       static std::mutex cache_mu;
