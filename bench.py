@@ -268,7 +268,10 @@ def main():
         wg = int(tc["task_queue_workgroups"])
         launches = max(dom.get("launches_per_eval", 1), 1)
         achieved = dom["achieved"]
-        cu_share = (wg / N_CUS) if (wg and dom["kernel"].startswith("dag_kernel")) else 1.0
+        # a task-queue launch shares the chip with the other slots' launches for its whole life: its roofline is its fair
+        # share of the chip, 1/slots (it is launched with a few more workgroups than that -- 96 for 3 slots -- which wait
+        # for a CU another slot's launch gives back; they do not add peak)
+        cu_share = (1.0 / nslots) if (wg and dom["kernel"].startswith("dag_kernel")) else 1.0
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"]
@@ -290,9 +293,10 @@ def main():
             "unit": dom["unit"],
             "frac": achieved / (peak * cu_share),
             "traffic": traffic,
-            "note": (f"the task-queue launch runs {wg} workgroups, one per CU, beside the other {nslots - 1} optimiser runs' launches: its "
-                     f"roofline is the fp64 MFMA peak of the {wg} CUs it occupies ({peak * cu_share:.1f} TFLOP/s); against the whole chip "
-                     f"the same launch reads {achieved / peak:.3f}; the whole fit (all launches of all runs) reaches whole_fit_frac_of_peak")
+            "note": (f"the task-queue launch ({wg} workgroups of 512 threads, one per CU) runs beside the other {nslots - 1} optimiser "
+                     f"runs' launches for its whole life: its roofline is its share of the chip, 1/{nslots} of the fp64 MFMA peak "
+                     f"({peak * cu_share:.1f} TFLOP/s); against the whole chip the same launch reads {achieved / peak:.3f}; the whole fit "
+                     f"(all launches of all runs) reaches whole_fit_frac_of_peak")
                     if cu_share < 1.0 else "whole-chip launch",
             "frac_of_chip_one_launch": achieved / peak,
             "launches_per_eval": launches,
@@ -351,6 +355,7 @@ def main():
             out["f32_side_line"] = {"workload": "C5: himmelblau d=2 n=2048 f32, one lml+gradient evaluation, single stream",
                                     "eval_ms": ph5["eval_graph_ms"],
                                     "eval_frac_of_fp32_peak": 2048 ** 3 * 1e-12 / (ph5["eval_graph_ms"] * 1e-3) / PEAK_FP32_MFMA_TFLOPS,
+                                    "dag_kernel<float> TFLOP/s (task queue: factor + inverse + K^-1)": (ph5["dag_gflop"] / ph5["dag_ms"]) if ph5["dag_ms"] > 0 else None,
                                     "gemm_kernel<float> 64/128-tile TFLOP/s": (g64 / m64) if m64 > 0 else None,
                                     "gemm_kernel<float> 32-tile TFLOP/s": (ph5["gemm32_gflop"] / ph5["gemm32_ms"]) if ph5["gemm32_ms"] > 0 else None,
                                     "peak_fp32_mfma": PEAK_FP32_MFMA_TFLOPS}
