@@ -456,7 +456,9 @@ struct Problem : ProblemBase {
       // inverse: two 128-deep tiles between consecutive diagonal blocks instead of products as deep as the node is wide
       // (critical path of one evaluation at n = 4096: 2.83 -> 2.02 ms, simulated).  Not bitwise equal to the launch path
       // (another order of operations); the recursion plan stays available (0) and is what the bitwise tests pin.
-      dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", 1) != 0;
+      // Above ~10k rows one evaluation is bound by the tile work, where the recursion's deeper tiles win again (n=8192: 10.3 /
+      // 9.9 ms recursion / right-looking, 12288: 31.4 / 32.0, 16384: 72.3 / 75.5).
+      dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
       std::array<int, 11> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", dag_nwg) : 0,
                                  env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                  env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1)};
