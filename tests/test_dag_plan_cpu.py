@@ -56,6 +56,39 @@ def test_flops_with_the_inverse_tiles_are_potrf_plus_potri():
     assert rc == 0 and info["gflop"] == pytest.approx(45.77 + 22.95, abs=0.03)
 
 
+@pytest.mark.parametrize("nb", list(range(1, 14)) + [16, 17, 24, 31, 32, 33, 48, 64, 80])
+def test_right_looking_plans_are_sound_for_every_block_count(nb):
+    # fine bit 3: the default plan (right-looking tile Cholesky + divide-and-conquer inverse), with and without the K^-1 tiles
+    ref = None
+    for bk in (16, 32):
+        for small_h, nwg, fine in [(4, 96, 1 | 4 | 8), (4, 256, 1 | 4 | 8), (8, 0, 1 | 8), (0, 3, 1 | 4 | 8), (4, 85, 4 | 8)]:
+            rc, info = plan(nb, bk, small_h, nwg, fine)
+            assert rc == 0, (nb, bk, small_h, nwg, fine, info["err"])
+            assert info["nleaf"] == nb
+            if fine & 4:
+                ref = ref or info["gflop"]
+                assert info["gflop"] == pytest.approx(ref, rel=1e-12)
+    # same algorithmic work as the recursion plan, whatever the order of operations
+    rc, rec = plan(nb, 16, 8, 85, 1 | 4)
+    assert rc == 0 and (ref is None or rec["gflop"] == pytest.approx(ref, rel=1e-12))
+
+
+def test_right_looking_plan_shortens_the_critical_path():
+    # n = 4096: between two diagonal blocks the recursion has a product as deep as the node is wide, the right-looking plan
+    # two 128-deep tiles (2.83 -> 2.03 ms simulated, 2.89 -> 2.19 ms measured for one evaluation)
+    _, rec = plan(32, nwg=256, fine=1 | 4)
+    _, rl = plan(32, small_h=4, nwg=256, fine=1 | 4 | 8)
+    assert rl["crit_us"] < 0.8 * rec["crit_us"] and rl["sim_us"] < 0.85 * rec["sim_us"]
+    assert rl["gflop"] == pytest.approx(68.72, abs=0.02)
+
+
+@pytest.mark.parametrize("fault", ["drop:40", "drop:700", "drop:3000", "drop:7000", "move:5000:10", "move:900:100"])
+def test_checker_rejects_broken_right_looking_plans(fault, monkeypatch):
+    monkeypatch.setenv("HBEGP_DAG_TEST_FAULT", fault)
+    rc, info = plan(32, small_h=4, nwg=96, fine=1 | 4 | 8)
+    assert rc == _lib.EINVAL and info["err"], fault
+
+
 def test_look_ahead_shortens_the_simulated_schedule():
     _, fine = plan(32, nwg=85, fine=1)
     _, coarse = plan(32, nwg=85, fine=0)
