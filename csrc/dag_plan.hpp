@@ -94,7 +94,7 @@ class DagBuilder {
   // right-looking plan: widest column range of a grouped update (measured at n = 4096, fit+predict/s: 4 -> 1.50, 8 -> 1.53,
   // 16 -> 1.53, 32 -> 1.57) and how many block columns ahead of the chain are updated column by column (1 -> 1.57, 2 -> 1.53,
   // 3 -> 1.51; one evaluation alone: 2.21 / 2.19 ms)
-  void set_rl(int group, int near) { rl_group_ = std::max(1, group); rl_near_ = std::max(1, near); }
+  void set_rl(int group, int near, bool lauum_split = true) { rl_group_ = std::max(1, group); rl_near_ = std::max(1, near); rl_lauum_split_ = lauum_split; }
   // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
   // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
   // carries the inverse (whole matrix only; the factor L lives in W3)
@@ -102,6 +102,7 @@ class DagBuilder {
     plan_ = DagPlan();
     top_lo_ = blo; top_hi_ = bhi;
     if (rl && blo == 0 && !full) {
+      lauum_split_ = rl_lauum_split_;
       build_rl(bhi, lauum);
     } else if (full && blo == 0) {
       build_full(bhi);
@@ -121,6 +122,7 @@ class DagBuilder {
   bool fine_;
   int crit_rows_ = 1;
   int rl_group_ = 32, rl_near_ = 1;
+  bool rl_lauum_split_ = true;
   DagPlan plan_;
   DagCosts cost_;
 
@@ -230,6 +232,8 @@ class DagBuilder {
 
   int top_lo_ = 0, top_hi_ = 0, top_mid_ = -1;
   DagGate top_right_all_;  // the right half of the top node is final (its X22)
+  DagGate top_left_all_;   // the left half of the top node is final (its X11)
+  bool lauum_split_ = false;  // right-looking plan: the K^-1 tiles of the top-left quadrant in two parts (not the launch path's bits)
   struct Sub {
     int lo = 0, hi = 0;
     std::vector<DagGate> rowfin;  // [j - lo]: row block j of X is final inside this subtree
@@ -321,17 +325,49 @@ class DagBuilder {
   void build_lauum(int nb, const Sub& root) {
     Op l{};
     l.flags = DAGF_ABUF | DAGF_BBUF | DAGF_AKM | DAGF_BKM | DAGF_CKINV;  // A = B = W2 (contraction along rows), C = K^-1
-    l.r0 = 0; l.r1 = nb; l.c0 = 0; l.c1 = nb; l.lower = true; l.k0 = 0; l.k1 = nb; l.klim = 4; l.tri_a = true; l.tri_b = true;
+    l.lower = true; l.klim = 4; l.tri_a = true; l.tri_b = true;
     const double g0 = plan_.gflop;
-    const std::vector<Tile> lt = tiles_of(l, false);
-    plan_.gflop_lauum = plan_.gflop - g0;
     double cu = 0;
-    for (const Tile& tl : lt) {
-      const DagTask tk = make(l, tl, &cu);
-      const bool quarter = top_mid_ >= 0 && tl.bj >= top_mid_;
-      push(tk, {quarter ? top_right_all_ : root.all}, -1, -1, cu);
-      plan_.n_lauum++;
-    }
+    const bool split = lauum_split_ && top_mid_ > 0;
+    for (int bi = 0; bi < nb; ++bi)
+      for (int bj = 0; bj <= bi; ++bj) {
+        Op one = l;
+        one.r0 = bi; one.r1 = bi + 1; one.c0 = bj; one.c1 = bj + 1;
+        if (split && bi < top_mid_) {
+          // top-left quadrant: the rows of X in the left half are final long before the top node's X21 is -- their part of
+          // the sum first (waits for the left half only), the X21 part on top of it (beta = 1).  On the evaluation's tail
+          // the deepest K^-1 tile is then half as deep (n/2 instead of n).
+          Op first = one;
+          first.k0 = 0; first.k1 = top_mid_;
+          const std::vector<Tile> t1 = tiles_of(first, false);
+          const int c1 = new_counter();
+          for (const Tile& tl : t1) {
+            const DagTask tk = make(first, tl, &cu);
+            push(tk, {top_left_all_}, c1, -1, cu);
+            plan_.n_lauum++;
+          }
+          Op second = one;
+          second.flags |= DAGF_ACC;
+          second.klim = 0; second.tri_a = second.tri_b = false;
+          second.k0 = top_mid_; second.k1 = nb;
+          const std::vector<Tile> t2 = tiles_of(second, false);
+          for (const Tile& tl : t2) {
+            const DagTask tk = make(second, tl, &cu);
+            push(tk, {root.all, DagGate{c1, (int)t1.size()}}, -1, -1, cu);
+            plan_.n_lauum++;
+          }
+        } else {
+          one.k0 = 0; one.k1 = nb;
+          const std::vector<Tile> lt = tiles_of(one, false);
+          const bool quarter = top_mid_ >= 0 && bj >= top_mid_;
+          for (const Tile& tl : lt) {
+            const DagTask tk = make(one, tl, &cu);
+            push(tk, {quarter ? top_right_all_ : root.all}, -1, -1, cu);
+            plan_.n_lauum++;
+          }
+        }
+      }
+    plan_.gflop_lauum = plan_.gflop - g0;
   }
 
   // ---------------------------------------------------------------------------------------------------------------
@@ -468,7 +504,7 @@ class DagBuilder {
     const bool small = std::max(mid - lo, hi - mid) <= small_h_;
     const Sub left = rl_inverse(lo, mid, nodes, leafc);
     const Sub right = rl_inverse(mid, hi, nodes, leafc);
-    if (lo == top_lo_ && hi == top_hi_) { top_mid_ = mid; top_right_all_ = right.all; }
+    if (lo == top_lo_ && hi == top_hi_) { top_mid_ = mid; top_right_all_ = right.all; top_left_all_ = left.all; }
     double cu = 0;
     // U = L21 X11 -> W1[2,1]   (A = W3, B = W2 with the contraction along rows)
     Op u{};
