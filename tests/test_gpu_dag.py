@@ -114,6 +114,7 @@ def test_concurrent_slots_share_the_chip_and_agree(monkeypatch):
     import threading
 
     monkeypatch.setenv("HBEGP_DAG", "1")  # the single-slot problem below would take the launch path at this size
+    monkeypatch.setenv("HBEGP_DAG_LAUUM_SPLIT", "0")  # ... and split its K^-1 tiles (another order of operations): same plan for both
     w = synth.make_workload("M", n=1500)
     X, y, theta = w["X"], w["y"], w["theta"]
     prob = gpr.Problem(X, y, n_slots=3)
