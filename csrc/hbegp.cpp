@@ -283,6 +283,8 @@ static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, st
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int DAG_MAX_VARIANTS = 4;  // task-queue launches sized for 1..4 busy slots; with more slots the last one is shared
+
 template <typename T>
 struct Slot {
   int dev = 0;
@@ -297,13 +299,14 @@ struct Slot {
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
   EvalOut* hOut = nullptr;   // pinned
-  hipGraphExec_t graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [target][want_grad]
+  hipGraphExec_t graph[DAG_MAX_VARIANTS + 1][2][2] = {};  // [task-queue variant][target][want_grad]
   // capture state (fit.rs:116-125)
   int best_idx = -1;  // which ping-pong buffer holds the best evaluation so far
   double best_lml = -std::numeric_limits<double>::infinity();
   int best_run = 0, best_eval = 0;
   std::vector<double> best_theta;
   int last_target = 0;  // buffer written by the most recent evaluation
+  int dag_variant = 1;  // which ordering / launch size the next task-queue launch uses (Problem::DagVariant)
   int dag_target = 0;   // alpha buffer the task-queue launch writes (its alpha / lml tasks)
   T* dag_kinv = nullptr;  // K^-1 buffer the task-queue launch writes (its X^T X tiles); null: factorisation only
   int gemm_ord = 0;     // ordinal of the next GEMM launch inside the current evaluation (indexes the static schedules)
@@ -333,9 +336,18 @@ struct Problem : ProblemBase {
   bool dag_lauum_ = false;                  // the tiles of K^-1 = X^T X are tasks of the queue too (no LAUUM launch)
   bool dag_rl_ = false;                     // right-looking plan (dag_plan.hpp build_rl): the factor L lives in W3
   double dag_gflop_lauum = 0;
-  std::vector<DagTask*> dag_tasks;          // per device
-  int dag_ntasks = 0, dag_nwg = 0;
-  std::vector<DagTask> dag_host_tasks;      // kept for the trace dump
+  // One ordering of the same task set per number of slots that are busy at the same time (variant v = 1..n_slots): a launch
+  // gets the share of the CUs that fits v concurrent launches, and its queue is ordered for that many workgroups.  Same
+  // tasks, same arithmetic, same bits for every variant -- only the order in which workgroups pull them differs.  A fit whose
+  // optimiser runs end at different times (early stopping, 8 runs over 3 slots) gives the remaining runs the freed CUs.
+  struct DagVariant {
+    int nwg = 0;
+    std::vector<DagTask*> tasks;            // per device
+    std::vector<DagTask> host_tasks;        // kept for the trace dump
+  };
+  std::vector<DagVariant> dag_var;          // [0] unused, [v] for v busy slots
+  std::unique_ptr<std::atomic<int>[]> busy_slots_;  // per device: slots inside an optimiser run (0: not known -> all of them)
+  int dag_ntasks = 0, dag_nwg = 0;          // dag_nwg: workgroups of the default variant (all slots busy)
   size_t dag_ctrl_bytes = 0;
   double dag_gflop = 0;
   // f32 (--use-32): the panel solve T = A21 L11^-T is a product with the explicit inverse X11, whose residual grows with
@@ -439,8 +451,10 @@ struct Problem : ProblemBase {
       // just given back (that slot is in its short kmat / alpha / gradient launches) and leave when their own queue is empty.
       // Measured, 3 slots, n=4096, fit+predict/s: 80 -> 1.58, 85 -> 1.62, 88 -> 1.64, 96 -> 1.68, 104 -> 1.64, 112 -> 1.68,
       // 120 -> 1.54, 128 -> 1.60, 170 -> 1.43, 256 -> 1.14.
-      const int share = n_slots <= 1 ? cus : std::max(8, (cus * env_int("HBEGP_DAG_OVERSUB", 112) / 100 / n_slots + 4) / 8 * 8);  // 3 slots: 96
-      dag_nwg = forced > 0 ? forced : std::max(1, std::min(cus, share));
+      auto share_of = [&](int busy) {
+        const int share = busy <= 1 ? cus : std::max(8, (cus * env_int("HBEGP_DAG_OVERSUB", 112) / 100 / busy + 4) / 8 * 8);  // 3 slots: 96
+        return forced > 0 ? forced : std::max(1, std::min(cus, share));
+      };
       // plans depend only on (blocks, stage depth, tiling and ordering knobs): the caller fits one model per generation with
       // slowly growing n, so they are kept (building + simulating the n=4096 queue costs ~15 ms of host time per fit)
       // HBEGP_DAG_FULL=1: kmat and the alpha / lml reductions as tasks of the same queue instead of launches around it (under
@@ -459,13 +473,14 @@ struct Problem : ProblemBase {
       // Above ~10k rows one evaluation is bound by the tile work, where the recursion's deeper tiles win again (n=8192: 10.3 /
       // 9.9 ms recursion / right-looking, 12288: 31.4 / 32.0, 16384: 72.3 / 75.5).
       dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
-      std::array<int, 12> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", dag_nwg) : 0,
-                                 env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
-                                 env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1), env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
       static std::mutex cache_mu;
       static std::map<std::array<int, 12>, std::shared_ptr<const DagPlan>> cache;
-      std::shared_ptr<const DagPlan> cached;
-      for (int attempt = 0; attempt < 2 && !cached; ++attempt) {
+      auto plan_for = [&](int nwg) {
+        std::array<int, 12> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
+                                   env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
+                                   env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1),
+                                   env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
+        std::shared_ptr<const DagPlan> cached;
         {
           std::lock_guard<std::mutex> lk(cache_mu);
           auto it = cache.find(key);
@@ -479,12 +494,14 @@ struct Problem : ProblemBase {
           if (cache.size() > 64) cache.clear();
           cache[key] = cached;
         }
-        if (cached->tasks.empty() && dag_rl_) {  // too many counters for 16-bit ids (n > ~12k): the recursion plan needs far fewer
-          dag_rl_ = false;
-          key[8] = 0;
-          key[2] = env_int("HBEGP_DAG_SMALLH", 8);
-          cached.reset();
-        }
+        return cached;
+      };
+      const int nvar = std::min(n_slots, DAG_MAX_VARIANTS);
+      dag_nwg = share_of(n_slots);  // the default variant: every slot busy
+      std::shared_ptr<const DagPlan> cached = plan_for(dag_nwg);
+      if (cached->tasks.empty() && dag_rl_) {  // too many counters for 16-bit ids (n > ~12k): the recursion plan needs far fewer
+        dag_rl_ = false;
+        cached = plan_for(dag_nwg);
       }
       const DagPlan& plan = *cached;
       if (plan.tasks.empty()) dag_ = dag_lauum_ = false;  // too many counters for 16-bit ids (n > 32k): launch-per-product path
@@ -501,11 +518,30 @@ struct Problem : ProblemBase {
         dag_gflop = plan.gflop;
         dag_gflop_lauum = plan.gflop_lauum;
         dag_ctrl_bytes = (sizeof(int) * (DAG_CTRL_WORDS + plan.totals.size()) + 15) / 16 * 16;
-        dag_tasks.assign(c->devs.size(), nullptr);
+        busy_slots_.reset(new std::atomic<int>[c->devs.size()]);
+        for (size_t di = 0; di < c->devs.size(); ++di) busy_slots_[di].store(0);
+        // the variants: [nvar] = the default (every slot busy), [v < nvar] for v busy slots (HBEGP_DAG_ADAPT=0: default only)
+        dag_var.assign(nvar + 1, DagVariant());
+        const bool adapt = env_int("HBEGP_DAG_ADAPT", 1) != 0 && forced <= 0;
+        for (int v = 1; v <= nvar; ++v) {
+          DagVariant& var = dag_var[v];
+          std::shared_ptr<const DagPlan> pv = cached;
+          var.nwg = dag_nwg;
+          if (v < nvar && adapt) {
+            var.nwg = std::min(share_of(v), dag_ntasks);
+            pv = plan_for(var.nwg);
+            if (pv->tasks.size() != plan.tasks.size()) { pv = cached; var.nwg = dag_nwg; }  // cannot happen: same task set
+          }
+          var.host_tasks = pv->tasks;
+          var.tasks.assign(c->devs.size(), nullptr);
+          for (size_t di = 0; di < c->devs.size(); ++di) {
+            HIPCHECK(hipSetDevice(c->devs[di]));
+            HIPCHECK(hipMalloc(&var.tasks[di], sizeof(DagTask) * pv->tasks.size()));
+            HIPCHECK(hipMemcpy(var.tasks[di], pv->tasks.data(), sizeof(DagTask) * pv->tasks.size(), hipMemcpyHostToDevice));
+          }
+        }
         for (size_t di = 0; di < c->devs.size(); ++di) {
           HIPCHECK(hipSetDevice(c->devs[di]));
-          HIPCHECK(hipMalloc(&dag_tasks[di], sizeof(DagTask) * plan.tasks.size()));
-          HIPCHECK(hipMemcpy(dag_tasks[di], plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
           for (auto& s : slots[di]) {
             if (dag_rl_ && !s.W3) {
               bool f3 = false;
@@ -518,7 +554,6 @@ struct Problem : ProblemBase {
               HIPCHECK(hipMemset(s.dag_trace, 0, sizeof(unsigned long long) * 5 * plan.tasks.size()));
             }
           }
-          dag_host_tasks = plan.tasks;
         }
       }
     }
@@ -539,9 +574,10 @@ struct Problem : ProblemBase {
       (void)hipSetDevice(ctx->devs[di]);
       for (auto& s : slots[di]) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
-        for (int a = 0; a < 2; ++a)
-          for (int b = 0; b < 2; ++b)
-            if (s.graph[a][b]) (void)hipGraphExecDestroy(s.graph[a][b]);
+        for (int v = 0; v <= DAG_MAX_VARIANTS; ++v)
+          for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+              if (s.graph[v][a][b]) (void)hipGraphExecDestroy(s.graph[v][a][b]);
         const size_t nnb = sizeof(T) * (size_t)np * np;
         g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb); g_pool.put(s.dev, s.W3, nnb);
         for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
@@ -551,13 +587,14 @@ struct Problem : ProblemBase {
         if (s.stream) (void)hipStreamDestroy(s.stream);
       }
       (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
-      if (di < dag_tasks.size()) (void)hipFree(dag_tasks[di]);
+      for (auto& var : dag_var)
+        if (di < var.tasks.size()) (void)hipFree(var.tasks[di]);
       if (di < scheds.size())
         for (auto& sc : scheds[di]) { (void)hipFree(sc.d_off); (void)hipFree(sc.d_items); }
     }
     slots.clear();
     scheds.clear();
-    dag_tasks.clear();
+    dag_var.clear();
     Xd.clear();
     yd.clear();
   }
@@ -698,8 +735,9 @@ struct Problem : ProblemBase {
     if (hipMemcpy(ctrl.data(), s.dag_ctrl, dag_ctrl_bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
     const int row = ctrl[1] - 1;
     fprintf(stderr, "task queue timeout: queue head %d of %d, first task that gave up: %d\n", ctrl[0], dag_ntasks, row);
-    if (row >= 0 && row < (int)dag_host_tasks.size()) {
-      const DagTask& t = dag_host_tasks[row];
+    const std::vector<DagTask>& host_tasks = dag_var[s.dag_variant].host_tasks;
+    if (row >= 0 && row < (int)host_tasks.size()) {
+      const DagTask& t = host_tasks[row];
       fprintf(stderr, "  kind %d flags %x row0 %d col0 %d k [%d, %d) waits:", t.kind, t.flags, t.row0, t.col0, t.kbeg, t.kend);
       for (int w = 0; w < t.nwait; ++w) fprintf(stderr, " c%d=%d/%d", t.wcnt[w], ctrl[DAG_CTRL_WORDS + t.wcnt[w]], t.wval[w]);
       fprintf(stderr, "\n");
@@ -717,7 +755,8 @@ struct Problem : ProblemBase {
       if (dry_) return;
       HIPCHECK(hipMemsetAsync(s.dag_ctrl, 0, dag_ctrl_bytes, s.stream));
       DagLaunch g{};
-      g.tasks = dag_tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
+      const DagVariant& var = dag_var[s.dag_variant];
+      g.tasks = var.tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
       g.mode = dag_full_ ? DAG_MODE_FULL : DAG_MODE_FACTOR;
       g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
       g.W3 = s.W3;
@@ -726,7 +765,7 @@ struct Problem : ProblemBase {
       g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
       g.trace = s.dag_trace;
       if (tm) tm->begin(PhaseTimer::DAG, 0, g.Kinv ? dag_gflop : dag_gflop - dag_gflop_lauum);
-      launch_dag<T>(g, dag_nwg, s.stream);
+      launch_dag<T>(g, var.nwg, s.stream);
       if (tm) tm->end();
       return;
     }
@@ -846,6 +885,7 @@ struct Problem : ProblemBase {
     Slot<T>& s = slots[di][si];
     HIPCHECK(hipSetDevice(s.dev));
     s.gemm_ord = 0;
+    s.dag_variant = variant_now(di);
     HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
     launch_reset_out(s.dOut, s.stream);
     s.dag_kinv = nullptr;  // the captured K^-1 stays as it is
@@ -938,13 +978,22 @@ struct Problem : ProblemBase {
     return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
   }
 
+  // The task-queue variant for an evaluation that starts now on device di: sized for the slots that are inside an optimiser
+  // run at this moment (a fit keeps the count; outside a fit every slot is assumed busy).
+  int variant_now(size_t di) const {
+    if (!dag_ || dag_var.size() < 2) return 1;
+    const int nvar = (int)dag_var.size() - 1;
+    const int busy = busy_slots_ ? busy_slots_[di].load(std::memory_order_relaxed) : 0;
+    return busy <= 0 ? nvar : std::min(busy, nvar);
+  }
   // Run one evaluation on (device index di, slot si) into ping-pong buffer `target`; blocks until the result is on the host.
   int run_eval(size_t di, int si, int target, bool want_grad, bool use_graph, double* lml, double* grad) {
     Slot<T>& s = slots[di][si];
     HIPCHECK(hipSetDevice(s.dev));
     static const bool graphs_on = env_int("HBEGP_NO_GRAPH", 0) == 0;
+    s.dag_variant = variant_now(di);
     if (use_graph && graphs_on) {
-      hipGraphExec_t& ge = s.graph[target][want_grad ? 1 : 0];
+      hipGraphExec_t& ge = s.graph[s.dag_variant][target][want_grad ? 1 : 0];
       if (!ge) {
         hipGraph_t gr = nullptr;
         HIPCHECK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
@@ -1004,8 +1053,9 @@ struct Problem : ProblemBase {
     HIPCHECK(hipEventCreate(&e0));
     HIPCHECK(hipEventCreate(&e1));
     HIPCHECK(hipEventRecord(e0, s.stream));
+    hipGraphExec_t timed_graph = s.graph[s.dag_variant][0][1];  // what the warm-up evaluation instantiated
     for (int r = 0; r < reps; ++r) {
-      if (s.graph[0][1]) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
+      if (timed_graph) HIPCHECK(hipGraphLaunch(timed_graph, s.stream));
       else enqueue_eval(s, (size_t)dev, 0, true, nullptr);  // HBEGP_NO_GRAPH=1
     }
     HIPCHECK(hipEventRecord(e1, s.stream));
@@ -1062,8 +1112,9 @@ struct Problem : ProblemBase {
     (void)hipEventDestroy(e1);
     if (s.dag_trace && getenv("HBEGP_DAG_TRACE")) {
       // one more graph replay on a quiet device, then dump: idx kind row col depth nwait | pulled ready computed published (ticks of 10 ns) | xcc hwid
-      if (s.graph[0][1]) HIPCHECK(hipGraphLaunch(s.graph[0][1], s.stream));
+      if (timed_graph) HIPCHECK(hipGraphLaunch(timed_graph, s.stream));
       HIPCHECK(hipStreamSynchronize(s.stream));
+      const std::vector<DagTask>& dag_host_tasks = dag_var[s.dag_variant].host_tasks;
       std::vector<unsigned long long> tr((size_t)5 * dag_ntasks);
       HIPCHECK(hipMemcpy(tr.data(), s.dag_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(getenv("HBEGP_DAG_TRACE"), "w")) {
@@ -1356,7 +1407,14 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   std::string err;
   std::mutex err_mu;
 
+  // how many slots of each device are inside an optimiser run: the task-queue launches are sized for that (Problem::DagVariant)
+  if (prob.busy_slots_)
+    for (int di = 0; di < ndev; ++di) prob.busy_slots_[di].store(std::min(runs_on[di], max_conc));
   auto worker = [&](int di, int si) {
+    struct Leave {
+      std::atomic<int>* busy;
+      ~Leave() { if (busy) busy->fetch_sub(1); }
+    } leave{prob.busy_slots_ ? &prob.busy_slots_[di] : nullptr};
     try {
       HIPCHECK(hipSetDevice(ctx->devs[di]));
       Slot<T>& s = prob.slots[di][si];

@@ -126,6 +126,25 @@ def test_runs_sharded_over_two_device_entries_give_the_same_model():
     ctx2.close()
 
 
+def test_launch_size_follows_the_busy_slots_without_changing_a_bit(monkeypatch):
+    # 5 optimiser runs over 3 slots that stop early at different evaluations: while fewer slots are busy the task-queue
+    # launches of the others are sized (and ordered) for that many -- the same tasks and the same arithmetic, so the model,
+    # its lml and every run's trajectory must be what the fixed launch size gives, bit for bit.
+    w = synth.make_workload("M", n=1400)
+    starts = synth.restart_points("M", w["lo"], w["hi"], 4)
+    got = {}
+    for adapt in ("0", "1"):
+        monkeypatch.setenv("HBEGP_DAG_ADAPT", adapt)
+        fk = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, maxeval=40, trace=True)
+        got[adapt] = (fk.lml, fk.theta.copy(), fk.arrays(), fk.trace["lml"].copy(), fk.trace["run"].copy(), fk.n_evals)
+        fk.release()
+    a, b = got["0"], got["1"]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[5] == b[5]
+    assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+    for r in range(5):
+        np.testing.assert_array_equal(a[3][a[4] == r], b[3][b[4] == r])
+
+
 def test_fit_quality_matches_scipy_lbfgsb_on_the_oracle():
     # The reference's optimiser (NLopt L-BFGS) is not available; scipy's L-BFGS-B on the CPU oracle's objective from the same
     # start points is an independent stand-in: the GPU fit must reach (at least) the same maximum of the lml.
