@@ -410,11 +410,12 @@ __device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
   }
 }
 
-// The diagonal block as a function of its own (DAG_LEAF_NOINLINE, the default): its register allocation then does not compete
-// with the tile pipeline's inside one kernel body (inlined: 10 spilled VGPRs in the kernel; as a call: none).  The block
-// itself is 1.5 us slower through the call, the tile tasks faster: fit 1.655 -> 1.677 fit+predict/s, one evaluation 2.17 -> 2.15 ms.
+// DAG_LEAF_NOINLINE=1 compiles the diagonal block as a function of its own: nothing spills in the kernel body then (10 VGPRs
+// otherwise) and the fit is 1.3 % faster -- but the results are NOT reproducible run to run in that build (12 identical fits
+// of config M gave 2-4 distinct lml values, the inlined build 1; tools/fit_bits.py): the block's LDS pointer becomes a flat
+// pointer across the call.  Kept for the record, off.
 #ifndef DAG_LEAF_NOINLINE
-#define DAG_LEAF_NOINLINE 1
+#define DAG_LEAF_NOINLINE 0
 #endif
 template <typename T>
 #if DAG_LEAF_NOINLINE

@@ -126,6 +126,20 @@ def test_runs_sharded_over_two_device_entries_give_the_same_model():
     ctx2.close()
 
 
+def test_fit_is_reproducible_run_to_run():
+    # The same fixed-work fit of config M (three concurrent optimiser runs through the task queue, 450 evaluations) six times:
+    # one model, bit for bit.  A build whose diagonal block was a called function failed this in 10-30 % of the fits
+    #  while every single-evaluation test passed.
+    w = synth.make_workload("M")
+    starts = synth.restart_points("M", w["lo"], w["hi"], 2)
+    seen = set()
+    for _ in range(6):
+        fk = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, maxeval=150, fixed_work=True)
+        seen.add((fk.lml, tuple(fk.theta)))
+        fk.release()
+    assert len(seen) == 1, seen
+
+
 def test_launch_size_follows_the_busy_slots_without_changing_a_bit(monkeypatch):
     # 5 optimiser runs over 3 slots that stop early at different evaluations: while fewer slots are busy the task-queue
     # launches of the others are sized (and ordered) for that many -- the same tasks and the same arithmetic, so the model,
