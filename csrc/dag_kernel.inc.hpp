@@ -412,19 +412,28 @@ __device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
 
 // DAG_LEAF_NOINLINE=1 compiles the diagonal block as a function of its own: nothing spills in the kernel body then (10 VGPRs
 // otherwise) and the fit is 1.3 % faster -- but the results are NOT reproducible run to run in that build (12 identical fits
-// of config M gave 2-4 distinct lml values, the inlined build 1; tools/fit_bits.py): the block's LDS pointer becomes a flat
-// pointer across the call.  Kept for the record, off.
+// of config M gave 2-4 distinct lml values, the inlined build 1 -- 40 of 40; tools/fit_bits.py).  Not the flat LDS pointer the
+// call produces: variant 2, where the function names the dynamic LDS itself and keeps ds_ accesses, does the same (5 distinct
+// values in 30 fits).  Cause not found; kept for the record, off.
 #ifndef DAG_LEAF_NOINLINE
 #define DAG_LEAF_NOINLINE 0
 #endif
 template <typename T>
-#if DAG_LEAF_NOINLINE
+#if DAG_LEAF_NOINLINE == 2
+// variant 2: the function names the workgroup's dynamic LDS itself, so the block keeps local-address-space (ds_) accesses
+__device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char*) {
+  extern __shared__ __align__(16) char leaf_smem[];
+  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, leaf_smem);
+}
+#elif DAG_LEAF_NOINLINE
 __device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
-#else
-__device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
-#endif
   leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, smem_raw);
 }
+#else
+__device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
+  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, smem_raw);
+}
+#endif
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
