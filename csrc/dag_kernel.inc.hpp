@@ -414,7 +414,9 @@ __device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
 // otherwise) and the fit is 1.3 % faster -- but the results are NOT reproducible run to run in that build (12 identical fits
 // of config M gave 2-4 distinct lml values, the inlined build 1 -- 40 of 40; tools/fit_bits.py).  Not the flat LDS pointer the
 // call produces: variant 2, where the function names the dynamic LDS itself and keeps ds_ accesses, does the same (5 distinct
-// values in 30 fits).  Cause not found; kept for the record, off.
+// values in 30 fits).  It needs the three optimiser runs side by side (one run at a time: 8 of 8 equal) and different theta per
+// run (the same theta evaluated 120 times on three slots at once: all outputs equal, tools/repro_probe.py).  Cause not found;
+// kept for the record, off.  The inlined build: 40 of 40 fits equal, also with other fits in between (FIT_BITS_MIX=1).
 #ifndef DAG_LEAF_NOINLINE
 #define DAG_LEAF_NOINLINE 0
 #endif
