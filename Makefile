@@ -17,10 +17,17 @@ build/hbegp.o: csrc/hbegp.cpp $(HDR)
 $(LIB): build/kernels.o build/hbegp.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lpthread
 
+# experimental builds of the kernels (diagnostics only; loaded with HBEGP_LIB=build/var/libhbegp_<NAME>.so):
+#   make variant NAME=noinline DEFS="-DDAG_LEAF_NOINLINE=1"
+variant: build/hbegp.o
+	@mkdir -p build/var
+	$(HIPCC) $(CXXFLAGS) $(DEFS) -c csrc/kernels.hip -o build/var/kernels_$(NAME).o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o build/var/libhbegp_$(NAME).so build/var/kernels_$(NAME).o build/hbegp.o -lpthread
+
 oracle: oracle/libgpr_oracle.so
 oracle/libgpr_oracle.so: oracle/gpr_oracle.c
 	gcc -O2 -fPIC -shared -o $@ $< -lm
 
 clean:
 	rm -rf build $(LIB) oracle/libgpr_oracle.so
-.PHONY: all clean oracle
+.PHONY: all clean oracle variant

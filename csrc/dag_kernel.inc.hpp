@@ -454,14 +454,22 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
   }
   for (;;) {
     if (t < 64) {
-      // wave 0: stage the task descriptor in LDS (one load instruction), then lane 0 waits for its dependencies
+      // wave 0: stage the task descriptor in LDS (one load instruction), then its lanes wait for the task's dependencies
       const int idx = __builtin_amdgcn_readfirstlane(next);
       int status = idx >= g.ntasks ? 2 : 0;
       if (g.trace && t == 0 && status == 0) g.trace[(size_t)idx * 5 + 0] = __builtin_amdgcn_s_memrealtime();
       if (status == 0) {
-        if (t < TASK_DW) ctl[4 + t] = pre;
-        const DagTask* tk = reinterpret_cast<const DagTask*>(ctl + 4);  // same wave: LDS accesses are in order
-        const int nw = tk->nwait;
+        if (t < TASK_DW) ctl[4 + t] = pre;  // for the other waves, which decode it behind the barrier below
+        // this wave decodes its wait list from the registers the descriptor arrived in (lane t holds dword t): nothing is read
+        // back from the LDS through another type before a barrier
+        const unsigned d5 = (unsigned)__builtin_amdgcn_readlane(pre, 5), d7 = (unsigned)__builtin_amdgcn_readlane(pre, 7);
+        const unsigned d8 = (unsigned)__builtin_amdgcn_readlane(pre, 8), d9 = (unsigned)__builtin_amdgcn_readlane(pre, 9);
+        const unsigned d10 = (unsigned)__builtin_amdgcn_readlane(pre, 10);
+        const int nw = (int)(d5 & 0xffffu);
+        const unsigned wc2 = (t & 2) ? d8 : d7, wv2 = (t & 2) ? d10 : d9;
+        const int my_wcnt = (int)((t & 1) ? wc2 >> 16 : wc2 & 0xffffu), my_wval = (int)((t & 1) ? wv2 >> 16 : wv2 & 0xffffu);
+        static_assert(DAG_MAXWAIT == 4 && offsetof(DagTask, nwait) == 20 && offsetof(DagTask, wcnt) == 28 && offsetof(DagTask, wval) == 36,
+                      "DagTask dword layout: nwait = low half of dword 5, wcnt = dwords 7-8, wval = dwords 9-10");
         // every look is ONE round trip: lane w reads counter w, lane 8 the evaluation's flag (a flag raised in this very
         // instant may be missed once: the task then computes on data nobody will use, the next task sees it).  Bounded
         // like dag_wait: 2 s of the 100 MHz clock, then the task is recorded, the flag set and every workgroup drains out.
@@ -469,7 +477,7 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
         unsigned long long t0 = 0;
         for (unsigned spins = 0;; ++spins) {
           bool ok = true;
-          if (t < nw) ok = __hip_atomic_load(g.ctrl + DAG_CTRL_WORDS + tk->wcnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)tk->wval[t];
+          if (t < nw) ok = __hip_atomic_load(g.ctrl + DAG_CTRL_WORDS + my_wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= my_wval;
           if (t == 8) inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const bool all_ok = __ballot(!ok) == 0ull;
           inf = __shfl(inf, 8, 64);

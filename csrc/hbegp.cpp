@@ -357,6 +357,7 @@ struct Problem : ProblemBase {
   bool refine_ = false;
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
+  int leaf_dbg_ = 0;                        // HBEGP_LEAF_DBG: debug bits of the diagonal-block kernel (16: helper waves start late)
 
   // single_shot: the problem runs one evaluation (extend): skip the static schedule tables, every GEMM launch is ad hoc
   Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_, bool single_shot = false) {
@@ -377,6 +378,7 @@ struct Problem : ProblemBase {
     // closer to the f64 result than LAPACK's f32 path (n=2048, cond 7e4: gradient 3e-6 vs 2e-5); refinement buys another
     // 1.3x on alpha / K^-1 for 26 % more time (measured), for kernel matrices beyond cond ~1e5
     refine_ = is_f32 && env_int("HBEGP_F32_REFINE", 0) != 0;
+    leaf_dbg_ = env_int("HBEGP_LEAF_DBG", 0) & 16;  // tests only; the bits that skip work stay with tools/leaf_bench
     const size_t nn = (size_t)np * np;
     Xd.assign(c->devs.size(), nullptr);
     yd.assign(c->devs.size(), nullptr);
@@ -650,7 +652,7 @@ struct Problem : ProblemBase {
     if (hi - lo == 1) {
       if (dry_) return;
       if (tm) tm->begin(PhaseTimer::LEAF);
-      launch_leaf<T>(s.W1, s.W2, np, lo, s.ldiag, &s.dOut->info, s.stream, 0, refine_ ? s.W3 : nullptr);
+      launch_leaf<T>(s.W1, s.W2, np, lo, s.ldiag, &s.dOut->info, s.stream, leaf_dbg_, refine_ ? s.W3 : nullptr);
       if (tm) tm->end();
       return;
     }
@@ -1744,13 +1746,15 @@ static int problem_debug_get(hbegp_problem* prob, int dev, int slot, int which, 
   if (!prob || !out) return fail(HBEGP_EINVAL, "NULL argument");
   auto* p = dynamic_cast<Problem<T>*>(prob->impl.get());
   if (!p) return fail(HBEGP_EINVAL, "element type mismatch");
-  if (dev < 0 || dev >= (int)p->slots.size() || slot < 0 || slot >= p->n_slots || (which != 1 && which != 2))
+  if (dev < 0 || dev >= (int)p->slots.size() || slot < 0 || slot >= p->n_slots || which < 1 || which > 4)
     return fail(HBEGP_EINVAL, "bad device/slot/which");
   GUARD_BEGIN
   Slot<T>& s = p->slots[dev][slot];
   HIPCHECK(hipSetDevice(s.dev));
   HIPCHECK(hipStreamSynchronize(s.stream));
-  HIPCHECK(hipMemcpy(out, which == 1 ? s.W1 : s.W2, sizeof(T) * (size_t)p->np * p->np, hipMemcpyDeviceToHost));
+  const T* src = which == 1 ? s.W1 : (which == 2 ? s.W2 : (which == 3 ? s.W3 : s.Kinv[s.last_target]));
+  if (!src) return fail(HBEGP_EINVAL, "this problem has no such work matrix");
+  HIPCHECK(hipMemcpy(out, src, sizeof(T) * (size_t)p->np * p->np, hipMemcpyDeviceToHost));
   return HBEGP_OK;
   GUARD_END
 }

@@ -492,6 +492,9 @@ template void launch_gemm<float>(const GemmLaunch&, int, hipStream_t);
 // =================================================================================================================
 // Leaf: 128x128 diagonal block.  L = chol(A) (lower), X = L^-1.
 // =================================================================================================================
+#ifndef LEAF_DIAG_COPY
+#define LEAF_DIAG_COPY 1
+#endif
 template <typename T>
 struct LeafGeom {
   static constexpr int S = 130;          // LDS row stride of the block image
@@ -567,10 +570,15 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
       }
     }
   }
+#if LEAF_DIAG_COPY
+  // the first diagonal 16x16 block once more, into Sc: the helper waves take the pivot rows from there (see the elimination)
+  if (t < 256) Sc[(t >> 4) * YS + (t & 15)] = (T)Ablk[(size_t)(t >> 4) * ld + (t & 15)];
+#endif
   __syncthreads();
 
   LEAF_STAMP(0);
-  auto update_block = [&](int i, int j, int pp) {  // A[i,j] -= L[i,pp] L[j,pp]^T
+  // diag_copy: the block is the next panel's diagonal block and helper waves will eliminate it a second time: keep a copy in Sc
+  auto update_block = [&](int i, int j, int pp, bool diag_copy = false) {  // A[i,j] -= L[i,pp] L[j,pp]^T
     acc_t acc = {0, 0, 0, 0};
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
@@ -581,7 +589,11 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       T* pc = &As[(i * 16 + C::crow(lane, r)) * S + j * 16 + m16];
-      *pc = *pc - acc[r];
+      const T v = *pc - acc[r];
+      *pc = v;
+#if LEAF_DIAG_COPY
+      if (diag_copy) Sc[C::crow(lane, r) * YS + m16] = v;
+#endif
     }
   };
 
@@ -656,9 +668,23 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
         const bool mine = helper ? (lane >= 16 && far < nfar) : (lane < nwin);
         const int row = helper ? ((lane < 16) ? 16 * p + lane : (far < nfar ? 16 * p + 64 + far : 16 * p))
                                : 16 * p + ((lane < nwin) ? lane : 0);
+        // dbg bit 4 (tests): the helper waves start ~3 us late -- longer than wave 0's whole elimination.  Results must not
+        // change: nothing a helper reads is written by another wave in this phase (tests/test_gpu_dag.py).
+        if ((dbg & 16) && helper) {
+          __builtin_amdgcn_s_sleep(127);
+          asm volatile("" ::: "memory");
+        }
         T a[16];
+#if LEAF_DIAG_COPY
+        // Wave 0 overwrites the pivot rows with L at the end of this phase, and no barrier orders a helper's reads of them
+        // before that: the helpers take them from the copy in Sc (written a phase earlier, behind a barrier) -- same values.
+        const T* src = (helper && lane < 16) ? Sc + lane * YS : As + row * S + p * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = src[j];
+#else
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = As[row * S + p * 16 + j];
+#endif
         bool bad = false;
         T rinv_own = T(0);
 #pragma unroll
@@ -721,7 +747,7 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
     if (dbg & 4) continue;
 
     // block column p+1 for every remaining block row (window rows from wave 0, far rows from the helpers)
-    for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p);
+    for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p, i == p + 1 && p + 1 < 4);
     __syncthreads();
     LEAF_STAMP(2 + 2 * p);
   }

@@ -174,7 +174,9 @@ double hbegp_minimize_by_gradient(hbegp_objective_fn f, void* user, double* x, c
                                   int n, int maxeval);
 
 /* ---- test hook: raw copy of a slot's work matrix after the last evaluation (np x np row-major, np = n rounded up to 128;
- * which = 1: W1 (Schur complements / U), 2: W2 (X = L^-1).  out holds np*np elements of the problem's type. */
+ * which = 1: W1 (Schur complements / U), 2: W2 (X = L^-1), 3: W3 (the factor L; right-looking task queue and f32
+ * refinement only), 4: the K^-1 buffer the last evaluation wrote (lower tiles, not mirrored).  out holds np*np elements of
+ * the problem's type. */
 int hbegp_problem_debug_get_f64(hbegp_problem* prob, int dev, int slot, int which, double* out);
 int hbegp_problem_debug_get_f32(hbegp_problem* prob, int dev, int slot, int which, float* out);
 

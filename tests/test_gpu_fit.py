@@ -140,6 +140,21 @@ def test_fit_is_reproducible_run_to_run():
     assert len(seen) == 1, seen
 
 
+def test_fit_is_reproducible_run_to_run_on_the_launch_path(monkeypatch):
+    # The same for the launch-per-product path (HBEGP_DAG=0) at n = 2048, where round 2 saw 2-5 distinct fitted lml values in
+    # 16 fits with three concurrent streams: the cause was the diagonal-block kernel's helper waves re-reading pivot rows that
+    # wave 0 overwrites in the same phase (tests/test_gpu_dag.py::test_diagonal_block_helper_waves_may_start_late pins the fix).
+    monkeypatch.setenv("HBEGP_DAG", "0")
+    w = synth.make_workload("M", n=2048)
+    starts = synth.restart_points("M", w["lo"], w["hi"], 2)
+    seen = set()
+    for _ in range(6):
+        fk = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, maxeval=150, fixed_work=True)
+        seen.add((fk.lml, tuple(fk.theta)))
+        fk.release()
+    assert len(seen) == 1, seen
+
+
 def test_launch_size_follows_the_busy_slots_without_changing_a_bit(monkeypatch):
     # 5 optimiser runs over 3 slots that stop early at different evaluations: while fewer slots are busy the task-queue
     # launches of the others are sized (and ordered) for that many -- the same tasks and the same arithmetic, so the model,
