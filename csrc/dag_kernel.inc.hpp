@@ -410,13 +410,12 @@ __device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
   }
 }
 
-// DAG_LEAF_NOINLINE=1 compiles the diagonal block as a function of its own: nothing spills in the kernel body then (10 VGPRs
-// otherwise) and the fit is 1.3 % faster -- but the results are NOT reproducible run to run in that build (12 identical fits
-// of config M gave 2-4 distinct lml values, the inlined build 1 -- 40 of 40; tools/fit_bits.py).  Not the flat LDS pointer the
-// call produces: variant 2, where the function names the dynamic LDS itself and keeps ds_ accesses, does the same (5 distinct
-// values in 30 fits).  It needs the three optimiser runs side by side (one run at a time: 8 of 8 equal) and different theta per
-// run (the same theta evaluated 120 times on three slots at once: all outputs equal, tools/repro_probe.py).  Cause not found;
-// kept for the record, off.  The inlined build: 40 of 40 fits equal, also with other fits in between (FIT_BITS_MIX=1).
+// DAG_LEAF_NOINLINE=1 compiles the diagonal block as a function of its own: nothing of it spills in the kernel body then (the
+// callee saves 25 registers on its stack instead).  Round 2 found that build not reproducible run to run and kept it off; the
+// cause (round 3, profiles/r03_leaf_race.txt) was not the call but a race inside leaf_body that every build had -- the helper
+// waves re-read pivot rows that wave 0 overwrites in the same phase -- and the called build merely lost it more often.  With
+// the pivot-row copy (LEAF_DIAG_COPY) the called build is bitwise reproducible too (0 deviations in 39,600 concurrent
+// evaluations, 5 without the copy).  Variant 2 names the workgroup's dynamic LDS itself and keeps ds_ accesses.
 #ifndef DAG_LEAF_NOINLINE
 #define DAG_LEAF_NOINLINE 0
 #endif

@@ -1377,12 +1377,25 @@ static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, 
 
 // ---------------------------------------------------------------------------------------------------------------
 // fit (fit.rs:71-176 + gradmin.rs:7-60)
+// The caller's options struct may be older (shorter) or newer (longer) than this library's: copy what both know, the rest
+// stays zero / NULL.  Nothing is read or written beyond min(struct_size, sizeof).
+static int read_fit_options(const hbegp_fit_options* in, hbegp_fit_options* out) {
+  *out = hbegp_fit_options{};
+  out->struct_size = sizeof(hbegp_fit_options);
+  if (!in) return HBEGP_OK;
+  if (in->struct_size < offsetof(hbegp_fit_options, maxeval) + sizeof(int) || in->struct_size > ((size_t)1 << 16))
+    return fail(HBEGP_EINVAL, "hbegp_fit_options.struct_size = %zu: set it to sizeof(hbegp_fit_options) (HBEGP_FIT_OPTIONS_INIT)",
+                in->struct_size);
+  memcpy(out, in, std::min(in->struct_size, sizeof(*out)));
+  return HBEGP_OK;
+}
+
 template <typename T>
 static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double nu, const double* theta0, const double* lo,
                   const double* hi, const double* starts, int n_restarts, const hbegp_fit_options* opt_in,
                   double* theta_best, double* lml_best, hbegp_model** model_out) {
   hbegp_fit_options opt{};
-  if (opt_in) opt = *opt_in;
+  if (int e = read_fit_options(opt_in, &opt)) return e;
   if (opt.maxeval <= 0) opt.maxeval = 150;
   const int p = d + 2;
   const int nruns = 1 + std::max(0, n_restarts);
@@ -1809,6 +1822,10 @@ int hbegp_problem_kmat_f32(hbegp_problem* prob, int dev, int slot, const double*
 int hbegp_fit_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, const double* theta0,
                   const double* lo, const double* hi, const double* starts, int n_restarts, const hbegp_fit_options* opt,
                   double* theta_best, double* lml_best, hbegp_model** model) {
+  {
+    hbegp_fit_options probe;
+    if (int e = read_fit_options(opt, &probe)) return e;  // before anything else: a mis-sized struct is a build problem
+  }
   if (int e = check_args(ctx, X, y, n, d, nu)) return e;
   if (!theta0 || !lo || !hi || (n_restarts > 0 && !starts)) return fail(HBEGP_EINVAL, "theta0/lo/hi/starts is NULL");
   GUARD_BEGIN
@@ -1818,6 +1835,10 @@ int hbegp_fit_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d
 int hbegp_fit_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta0,
                   const double* lo, const double* hi, const double* starts, int n_restarts, const hbegp_fit_options* opt,
                   double* theta_best, double* lml_best, hbegp_model** model) {
+  {
+    hbegp_fit_options probe;
+    if (int e = read_fit_options(opt, &probe)) return e;  // before anything else: a mis-sized struct is a build problem
+  }
   if (int e = check_args(ctx, X, y, n, d, nu)) return e;
   if (!theta0 || !lo || !hi || (n_restarts > 0 && !starts)) return fail(HBEGP_EINVAL, "theta0/lo/hi/starts is NULL");
   GUARD_BEGIN

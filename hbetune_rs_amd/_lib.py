@@ -22,7 +22,10 @@ class HbegpError(RuntimeError):
 
 
 class FitOptions(C.Structure):
+    """hbegp_fit_options; `struct_size` is filled in by __init__ (the library copies min(struct_size, its own size))."""
+
     _fields_ = [
+        ("struct_size", C.c_size_t),
         ("maxeval", C.c_int),
         ("fixed_work", C.c_int),
         ("lbfgs_memory", C.c_int),
@@ -35,6 +38,10 @@ class FitOptions(C.Structure):
         ("n_evals", C.POINTER(C.c_int)),
         ("n_not_pd", C.POINTER(C.c_int)),
     ]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(FitOptions)
 
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)

@@ -29,11 +29,14 @@
 #ifndef HBEGP_H
 #define HBEGP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define HBEGP_VERSION 102 /* 0.1.2: + hbegp_problem_time_concurrent, hbegp_fit_options.n_evals / n_not_pd, hbegp_debug_dag_plan */
+#define HBEGP_VERSION 200 /* 0.2.0: hbegp_fit_options starts with struct_size (the struct may grow at its end without breaking
+                             callers built against an older header); hbegp_problem_debug_get which = 3, 4 */
 
 enum {
   HBEGP_OK = 0,
@@ -106,6 +109,10 @@ int hbegp_problem_time_concurrent(hbegp_problem* prob, int dev, const double* th
 
 /* ---- fit / extend: mirrors FittedKernel::new / ::extend (fit.rs:18-68, 71-176) --------------------- */
 typedef struct hbegp_fit_options {
+  /* sizeof(hbegp_fit_options) in the header the CALLER was compiled against (use HBEGP_FIT_OPTIONS_INIT).  The library reads
+   * and writes through min(struct_size, its own sizeof) bytes only: members beyond the caller's struct are taken as zero /
+   * NULL, so the struct can grow at its end.  0 or a size that does not cover `maxeval` is HBEGP_EINVAL. */
+  size_t struct_size;
   int maxeval;      /* evaluations per optimiser run; the reference uses 150 (gradmin.rs:54) */
   int fixed_work;   /* 0: stop a run when the optimiser converges; 1: keep evaluating up to maxeval (bench) */
   int lbfgs_memory; /* history pairs, 0 = default (10) */
@@ -122,6 +129,7 @@ typedef struct hbegp_fit_options {
   int* n_evals;     /* out (may be NULL): evaluations run, all optimiser runs together */
   int* n_not_pd;    /* out (may be NULL): evaluations whose kernel matrix was not positive definite (objective +inf, fit.rs:105-112) */
 } hbegp_fit_options;
+#define HBEGP_FIT_OPTIONS_INIT { sizeof(hbegp_fit_options) }
 
 /* Maximise the log marginal likelihood over theta in [ln lo, ln hi] with 1 + n_restarts bounded L-BFGS runs:
  * run 0 starts at theta0, run r>0 at starts[(r-1)*p .. ] (uniform draws in log-bounds made by the caller's RNG,

@@ -86,7 +86,7 @@ class FittedKernel {
     const int p = d + 2;
     if ((int)theta0.size() != p || (int)b.lo.size() != p || (int)b.hi.size() != p || starts.size() % p != 0)
       throw Error(HBEGP_EINVAL, "theta0 / bounds / starts have the wrong length");
-    hbegp_fit_options opt{};
+    hbegp_fit_options opt = HBEGP_FIT_OPTIONS_INIT;
     opt.maxeval = maxeval;
     FittedKernel fk;
     fk.n_ = n; fk.d_ = d; fk.theta_.resize(p);

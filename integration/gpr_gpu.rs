@@ -47,6 +47,8 @@ pub struct HbegpModel {
 /// `hbegp_fit_options` (include/hbegp.h)
 #[repr(C)]
 pub struct HbegpFitOptions {
+    /// `size_of::<HbegpFitOptions>()`: the library copies min(struct_size, its own size), so the struct may grow at its end
+    pub struct_size: usize,
     pub maxeval: c_int,
     pub fixed_work: c_int,
     pub lbfgs_memory: c_int,
@@ -228,8 +230,8 @@ impl Context {
     /// the axis; no collective).  `HBEGP_DEVICES=k` limits the count.
     fn open() -> Result<std::rc::Rc<Context>, Error> {
         let abi = unsafe { hbegp_version() };
-        if abi < 102 {
-            return Err(Error::Backend(format!("libhbegp ABI {} is older than this binding (102)", abi)));
+        if abi < 200 {
+            return Err(Error::Backend(format!("libhbegp ABI {} is older than this binding (200: hbegp_fit_options.struct_size)", abi)));
         }
         let mut count = unsafe { hbegp_device_count() };
         if let Some(limit) = std::env::var("HBEGP_DEVICES").ok().and_then(|s| s.parse::<c_int>().ok()) {
@@ -649,6 +651,7 @@ impl<A: GpuScalar> Estimator<A> for EstimatorGpu {
         let x_train = x.as_standard_layout();
         let y_train = y_train.as_standard_layout();
         let opt = HbegpFitOptions {
+            struct_size: std::mem::size_of::<HbegpFitOptions>(),
             maxeval: self.maxeval as c_int,
             fixed_work: 0,
             lbfgs_memory: 0,

@@ -56,6 +56,36 @@ int main() {
       if (std::fabs(aa[i] - fa[i]) > 1e-9 * (1.0 + std::fabs(fa[i]))) { ++bad; break; }
     if (std::fabs(a.lml() - f.lml()) > 1e-9 * std::fabs(f.lml())) ++bad;
   }
+  // ABI growth (hbegp.h: hbegp_fit_options.struct_size): a caller compiled against an OLDER, shorter options struct -- here one
+  // that ends behind trace_count, as 0.1.1's did -- must be served without the library reading or writing past it.
+  {
+    struct OldOptions {
+      size_t struct_size;
+      int maxeval, fixed_work, lbfgs_memory, trace_cap;
+      double *trace_theta, *trace_lml, *trace_grad;
+      int* trace_run;
+      int* trace_count;
+    };
+    struct {
+      OldOptions o;
+      void* guard[2];  // where n_evals / n_not_pd of the current struct would lie: wild pointers the library must not see
+    } mem;
+    static_assert(sizeof(OldOptions) < sizeof(hbegp_fit_options), "the old layout is a strict prefix");
+    mem.o = OldOptions{sizeof(OldOptions), 20, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    mem.guard[0] = reinterpret_cast<void*>(0x10);
+    mem.guard[1] = reinterpret_cast<void*>(0x18);
+    double tb[3], lb = 0;
+    hbegp_model* m = nullptr;
+    const int rc = hbegp_fit_f64(ctx.get(), xs, ys, 4, 1, 2.5, theta0.data(), b.lo.data(), b.hi.data(), nullptr, 0,
+                                 reinterpret_cast<const hbegp_fit_options*>(&mem.o), tb, &lb, &m);
+    if (rc != HBEGP_OK || !m || !std::isfinite(lb)) ++bad;
+    if (m) hbegp_model_release(m);
+    // and a struct whose size field was never set is refused instead of being trusted
+    hbegp_fit_options zero{};
+    hbegp_model* m2 = nullptr;
+    if (hbegp_fit_f64(ctx.get(), xs, ys, 4, 1, 2.5, theta0.data(), b.lo.data(), b.hi.data(), nullptr, 0, &zero, tb, &lb, &m2) != HBEGP_EINVAL) ++bad;
+    if (m2) hbegp_model_release(m2);
+  }
   std::printf("lml=%.6f amplitude=%.4f ell=%.4f noise=%.5f bad=%d threw=%d alpha0=%.4f\n", fk.lml(), fk.amplitude(), fk.length_scale()[0],
               fk.noise(), bad, (int)threw, fk.alpha()[0]);
   return (bad == 0 && threw) ? 0 : 1;

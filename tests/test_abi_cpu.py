@@ -26,7 +26,32 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/hbegp.h but not exported by libhbegp.so"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.hbegp_version() == 102
+    assert lib.hbegp_version() == 200
+
+
+def test_fit_options_carry_their_size():
+    # hbegp.h: the options struct starts with struct_size so that it can grow at its end; the ctypes mirror has the header's
+    # layout (size_t, 4 ints, 7 pointers) and a struct whose size was never set is refused before anything else is looked at
+    import ctypes as C
+
+    assert C.sizeof(_lib.FitOptions) == 8 + 4 * 4 + 7 * 8
+    assert _lib.FitOptions().struct_size == C.sizeof(_lib.FitOptions)
+    text = open(os.path.join(ROOT, "include", "hbegp.h")).read()
+    body = re.search(r"typedef struct hbegp_fit_options \{(.*?)\} hbegp_fit_options;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(\w+);", body)
+    assert names == [f[0] for f in _lib.FitOptions._fields_]
+    lib = _lib.load()
+    bad = _lib.FitOptions()
+    bad.struct_size = 0
+    x = np.zeros(4)
+    rc = lib.hbegp_fit_f64(None, _lib.dptr(x), _lib.dptr(x), 4, 1, 2.5, _lib.dptr(x), _lib.dptr(x), _lib.dptr(x), None, 0, C.byref(bad),
+                           None, None, None)
+    assert rc == _lib.EINVAL and "struct_size" in _lib.last_error()
+    ok = _lib.FitOptions()
+    rc = lib.hbegp_fit_f64(None, _lib.dptr(x), _lib.dptr(x), 4, 1, 2.5, _lib.dptr(x), _lib.dptr(x), _lib.dptr(x), None, 0, C.byref(ok),
+                           None, None, None)
+    assert rc == _lib.EINVAL and "struct_size" not in _lib.last_error()  # the NULL context is what is wrong now
 
 
 def test_no_cpu_fallback_without_gpu():
