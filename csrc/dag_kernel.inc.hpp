@@ -15,7 +15,8 @@
 //     barrier, then one lane bumps the counter.  The consumer polls with relaxed agent-scope loads from one lane, runs
 //     ONE agent-scope acquire (buffer_inv sc1: drops this CU's L1 lines), waits for it, and the workgroup meets at a
 //     barrier before any wave loads operands with plain loads.
-//   * Every wait is bounded (2 s of the constant 100 MHz clock): on expiry the task index is recorded, info becomes
+//   * Every wait is bounded (DagLaunch::wait_ticks of the constant 100 MHz clock; the host sets max(2 s, 200 x the plan's
+//     simulated makespan), HBEGP_DAG_WAIT_S overrides -- the clock keeps running while a queue is preempted): on expiry the task index is recorded, info becomes
 //     DAG_INFO_TIMEOUT and every workgroup drains out -- a scheduling bug ends in an error code, not in a hung GPU.
 //   * Not positive definite (info > 0, set by a diagonal block): later tasks skip their work but still bump their
 //     counters, so the queue drains at once.
@@ -103,6 +104,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   // The 64x64 tile keeps them in registers (8); the 128x64 tile (16: the kernel's diagonal block would spill) parks them in
   // the LDS behind the stage buffers until the epilogue.  Measured on the 128-deep 128x64 update: 13.8 -> 9.9 us.
   const bool accum = (flags & DAGF_ACC) != 0;
+  const bool cinit = sizeof(T) == 8 && (flags & DAGF_CINIT) != 0;  // the old values start the accumulation (engine.hpp)
   constexpr bool PREFETCH_C = TA == 64;
   constexpr int STASH_OFF = 2 * (G::LDSA + G::LDSB);  // in elements of T, behind [A buf0 | A buf1 | B buf0 | B buf1]
   static_assert((size_t)(STASH_OFF + TA * TB) * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stash must fit in front of the control words");
@@ -116,6 +118,16 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           cold[a][b][r] = accum ? Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16] : T(0);
+    if constexpr (sizeof(T) == 8) {
+      if (cinit) {
+#pragma unroll
+        for (int a = 0; a < TMA; ++a)
+#pragma unroll
+          for (int b = 0; b < TMB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = cold[a][b][r];
+      }
+    }
   }
 
   // f32: fp64 totals per F32_CHUNK contraction elements, exactly as gemm_kernel does (same chunk boundaries: same bits)
@@ -200,12 +212,26 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) cst[a][b][r] = Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16];
         store_stage(0, ra0, rb0);
+        bool stash = true;
+        if constexpr (sizeof(T) == 8) {
+          if (cinit) {
+            stash = false;
 #pragma unroll
-        for (int a = 0; a < TMA; ++a)
+            for (int a = 0; a < TMA; ++a)
 #pragma unroll
-          for (int b = 0; b < TMB; ++b)
+              for (int b = 0; b < TMB; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t] = cst[a][b][r];
+                for (int r = 0; r < 4; ++r) acc[a][b][r] = cst[a][b][r];
+          }
+        }
+        if (stash) {
+#pragma unroll
+          for (int a = 0; a < TMA; ++a)
+#pragma unroll
+            for (int b = 0; b < TMB; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t] = cst[a][b][r];
+        }
       } else {
         store_stage(0, ra0, rb0);
       }
@@ -241,9 +267,9 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
         else v = acc[a][b][r];
         if (neg) v = -v;
         if constexpr (PREFETCH_C) {
-          if (accum) v += cold[a][b][r];
+          if (accum && !cinit) v += cold[a][b][r];
         } else {
-          if (accum) v += lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t];
+          if (accum && !cinit) v += lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t];
         }
         gstore<true>(p, v);
       }
@@ -471,7 +497,8 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
                       "DagTask dword layout: nwait = low half of dword 5, wcnt = dwords 7-8, wval = dwords 9-10");
         // every look is ONE round trip: lane w reads counter w, lane 8 the evaluation's flag (a flag raised in this very
         // instant may be missed once: the task then computes on data nobody will use, the next task sees it).  Bounded
-        // like dag_wait: 2 s of the 100 MHz clock, then the task is recorded, the flag set and every workgroup drains out.
+        // g.wait_ticks of the 100 MHz clock (host: at least 2 s, more for long plans), then the task is recorded, the flag set and
+        // every workgroup drains out.
         int inf = 0;
         unsigned long long t0 = 0;
         for (unsigned spins = 0;; ++spins) {
@@ -483,7 +510,7 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
           if (all_ok || inf < 0) break;
           if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
           __builtin_amdgcn_s_sleep(1);
-          if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+          if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > g.wait_ticks) {
             if (t == 0) {
               int expected = 0;
               __hip_atomic_compare_exchange_strong(g.ctrl + 1, &expected, idx + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

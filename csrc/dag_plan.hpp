@@ -233,7 +233,7 @@ class DagBuilder {
   int top_lo_ = 0, top_hi_ = 0, top_mid_ = -1;
   DagGate top_right_all_;  // the right half of the top node is final (its X22)
   DagGate top_left_all_;   // the left half of the top node is final (its X11)
-  bool lauum_split_ = false;  // right-looking plan: the K^-1 tiles of the top-left quadrant in two parts (not the launch path's bits)
+  bool lauum_split_ = false;  // right-looking plan: the K^-1 tiles of the top-left quadrant in two parts (DAGF_CINIT: the same bits as one part)
   struct Sub {
     int lo = 0, hi = 0;
     std::vector<DagGate> rowfin;  // [j - lo]: row block j of X is final inside this subtree
@@ -328,7 +328,7 @@ class DagBuilder {
     l.lower = true; l.klim = 4; l.tri_a = true; l.tri_b = true;
     const double g0 = plan_.gflop;
     double cu = 0;
-    const bool split = lauum_split_ && top_mid_ > 0;
+    const bool split = lauum_split_ && top_mid_ > 0 && bk_ == 16;  // f64 only: an f32 partial sum would be rounded on its way through memory
     for (int bi = 0; bi < nb; ++bi)
       for (int bj = 0; bj <= bi; ++bj) {
         Op one = l;
@@ -347,7 +347,7 @@ class DagBuilder {
             plan_.n_lauum++;
           }
           Op second = one;
-          second.flags |= DAGF_ACC;
+          second.flags |= DAGF_ACC | DAGF_CINIT;  // continues the first part's accumulation: the same bits as one undivided tile
           second.klim = 0; second.tri_a = second.tri_b = false;
           second.k0 = top_mid_; second.k1 = nb;
           const std::vector<Tile> t2 = tiles_of(second, false);

@@ -94,6 +94,9 @@ enum : uint16_t {
   DAGF_A3 = 256,   // operand A lives in W3 (overrides DAGF_ABUF)
   DAGF_B3 = 512,
   DAGF_C3 = 1024,  // the result goes to W3 (overrides DAGF_CBUF)
+  // with DAGF_ACC (f64 only, no DAGF_NEG): the old values of the output tile START the accumulation instead of being added at the
+  // end -- the second part of a contraction split in two then continues the first part's MFMA chain bit for bit
+  DAGF_CINIT = 2048,
 };
 constexpr int DAG_MAXWAIT = 4;
 constexpr int DAG_MAXSIG = 3;
@@ -139,6 +142,7 @@ struct DagLaunch {
   void* alpha;            // np
   EvalOut* out;
   unsigned long long* trace;  // optional (diagnostics): per task [pulled, inputs ready, computed, published] on the 100 MHz clock, then the CU id
+  unsigned long long wait_ticks;  // bound of one dependency wait in ticks of the 100 MHz clock (host: from the plan's simulated makespan)
 };
 template <typename T>
 void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);

@@ -348,6 +348,7 @@ struct Problem : ProblemBase {
   std::vector<DagVariant> dag_var;          // [0] unused, [v] for v busy slots
   std::unique_ptr<std::atomic<int>[]> busy_slots_;  // per device: slots inside an optimiser run (0: not known -> all of them)
   int dag_ntasks = 0, dag_nwg = 0;          // dag_nwg: workgroups of the default variant (all slots busy)
+  unsigned long long dag_wait_ticks_ = 200000000ull;  // bound of one dependency wait (100 MHz ticks), see init()
   size_t dag_ctrl_bytes = 0;
   double dag_gflop = 0;
   // f32 (--use-32): the panel solve T = A21 L11^-T is a product with the explicit inverse X11, whose residual grows with
@@ -441,11 +442,11 @@ struct Problem : ProblemBase {
     dag_ = (dag_env < 0 ? np / NB >= dag_min_blocks : dag_env != 0) && !adhoc_ && np / NB >= 2;
     if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
-      int cus = 256;
-      {
+      int cus = 1 << 30;  // the launch sizes are shared by the devices of the context: size them for the smallest one
+      for (int dev : c->devs) {
         hipDeviceProp_t prop;
-        HIPCHECK(hipGetDeviceProperties(&prop, c->devs[0]));
-        cus = std::max(1, prop.multiProcessorCount);
+        HIPCHECK(hipGetDeviceProperties(&prop, dev));
+        cus = std::min(cus, std::max(1, prop.multiProcessorCount));
       }
       const int forced = env_int("HBEGP_DAG_WG", 0);
       // Concurrent slots: each launch gets a little more than its share of the CUs (a multiple of 8: the dispatcher deals
@@ -520,6 +521,14 @@ struct Problem : ProblemBase {
         dag_gflop = plan.gflop;
         dag_gflop_lauum = plan.gflop_lauum;
         dag_ctrl_bytes = (sizeof(int) * (DAG_CTRL_WORDS + plan.totals.size()) + 15) / 16 * 16;
+        // A dependency wait longer than this is reported as a scheduling bug (info = -2).  The clock runs on while the queue is
+        // preempted or time-sliced (another process, a profiler serialising dispatches) and single waits grow with the plan, so
+        // the bound follows the plan: 200 x its simulated makespan with every slot sharing the chip, at least 2 s.
+        {
+          const double wait_s = std::max(2.0, 200.0 * plan.sim_us * 1e-6 * std::max(1, n_slots));
+          const double forced_s = getenv("HBEGP_DAG_WAIT_S") ? atof(getenv("HBEGP_DAG_WAIT_S")) : 0.0;
+          dag_wait_ticks_ = (unsigned long long)((forced_s > 0 ? forced_s : wait_s) * 1e8);
+        }
         busy_slots_.reset(new std::atomic<int>[c->devs.size()]);
         for (size_t di = 0; di < c->devs.size(); ++di) busy_slots_[di].store(0);
         // the variants: [nvar] = the default (every slot busy), [v < nvar] for v busy slots (HBEGP_DAG_ADAPT=0: default only)
@@ -766,6 +775,7 @@ struct Problem : ProblemBase {
       g.X = Xd[di]; g.y = yd[di]; g.P = s.dP; g.n = n; g.d = d; g.nu2 = nu2;
       g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
       g.trace = s.dag_trace;
+      g.wait_ticks = dag_wait_ticks_;
       if (tm) tm->begin(PhaseTimer::DAG, 0, g.Kinv ? dag_gflop : dag_gflop - dag_gflop_lauum);
       launch_dag<T>(g, var.nwg, s.stream);
       if (tm) tm->end();
@@ -1030,6 +1040,15 @@ struct Problem : ProblemBase {
       throw HipError{hipErrorLaunchFailure, "evaluation: the lml/gradient kernels did not run", __LINE__};
     *lml = s.hOut->lml;
     if (grad) for (int j = 0; j < p; ++j) grad[j] = s.hOut->grad[j];
+    // the outputs were poisoned with NaN before the launches: a block of the gradient reduction that never ran, or a genuinely
+    // non-finite trace, must not reach the optimiser as a number
+    bool finite = std::isfinite(*lml);
+    if (grad) for (int j = 0; j < p; ++j) finite = finite && std::isfinite(grad[j]);
+    if (!finite) {  // handled like a failed factorisation (lml.rs:47-50 -> fit.rs:105-112): objective +inf, zero gradient, never captured
+      *lml = -std::numeric_limits<double>::infinity();
+      if (grad) for (int j = 0; j < p; ++j) grad[j] = 0.0;
+      return HBEGP_NOT_PD;
+    }
     return HBEGP_OK;
   }
 

@@ -114,7 +114,6 @@ def test_concurrent_slots_share_the_chip_and_agree(monkeypatch):
     import threading
 
     monkeypatch.setenv("HBEGP_DAG", "1")  # the single-slot problem below would take the launch path at this size
-    monkeypatch.setenv("HBEGP_DAG_LAUUM_SPLIT", "0")  # ... and split its K^-1 tiles (another order of operations): same plan for both
     w = synth.make_workload("M", n=1500)
     X, y, theta = w["X"], w["y"], w["theta"]
     prob = gpr.Problem(X, y, n_slots=3)
@@ -192,3 +191,17 @@ def test_diagonal_block_helper_waves_may_start_late(n, monkeypatch):
     want = O.lml_with_gradient(X, y, math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:]), 2.5)
     assert abs(got[0][0][0] - want["lml"]) <= 1e-8 * max(1.0, abs(want["lml"]))
     np.testing.assert_allclose(got[0][0][1], want["grad"], rtol=0, atol=1e-8 * max(1.0, np.abs(want["grad"]).max()))
+
+
+@pytest.mark.parametrize("n", [1100, 2048])
+def test_split_kinv_tiles_continue_the_same_accumulation(n, monkeypatch):
+    # One evaluation alone forms the top-left K^-1 tiles in two parts (HBEGP_DAG_LAUUM_SPLIT, the default for a single slot;
+    # a fit's slots do not): the second part starts its MFMA chain from the first part's stored sums (DAGF_CINIT), so both
+    # orders give the same bits -- `extend` after `estimate` is bit-comparable with the fit's own evaluation of that theta.
+    w = synth.make_workload("M", n=n)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    one = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_LAUUM_SPLIT=0)
+    two = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_LAUUM_SPLIT=1)
+    for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(one, two):
+        assert r0[0] == r1[0] and np.array_equal(r0[1], r1[1])
+        assert np.array_equal(a0, a1) and np.array_equal(k0, k1) and np.array_equal(l0, l1)

@@ -17,7 +17,7 @@ from hbetune_rs_amd import gpr, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 w = synth.make_workload("M", n=n)
 os.environ["HBEGP_DAG"] = "1"
-os.environ["HBEGP_DAG_LAUUM_SPLIT"] = "0"
+os.environ["HBEGP_DAG_LAUUM_SPLIT"] = "0"  # same task set in A, B and C
 out = {"n": n}
 p3 = gpr.Problem(w["X"], w["y"], n_slots=3)
 b = p3.time_concurrent(w["theta"], reps=8)

@@ -14,7 +14,6 @@ w = synth.make_workload("M", n=n)
 X, y, theta0 = w["X"], w["y"], w["theta"]
 rng = np.random.default_rng(7)
 thetas = theta0[None, :] + 0.15 * rng.standard_normal((3 * rounds, len(theta0)))
-os.environ.setdefault("HBEGP_DAG_LAUUM_SPLIT", "0")  # the single-slot reference must use the slots' order of operations
 if os.environ.get("SOAK_DAG"):
     os.environ["HBEGP_DAG"] = os.environ["SOAK_DAG"]
 else:

@@ -27,7 +27,6 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 mode = sys.argv[3] if len(sys.argv) > 3 else "rand"
 maxdump = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 NS = 3
-os.environ.setdefault("HBEGP_DAG_LAUUM_SPLIT", "0")  # the quiet single-slot reference uses the slots' order of operations
 
 w = synth.make_workload("M", n=n)
 X, y, theta0 = w["X"], w["y"], w["theta"]

@@ -9,7 +9,6 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 w = synth.make_workload("M", n=n)
 os.environ.setdefault("HBEGP_DAG", "1")
-os.environ.setdefault("HBEGP_DAG_LAUUM_SPLIT", "0")
 for slots in (1, 3):
     prob = gpr.Problem(w["X"], w["y"], n_slots=slots)
     ref = None
