@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CXXFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result
 LIB = hbetune_rs_amd/libhbegp.so
 SRC = csrc/kernels.hip csrc/hbegp.cpp
-HDR = csrc/engine.hpp csrc/lbfgsb.hpp csrc/dag_plan.hpp csrc/dag_kernel.inc.hpp include/hbegp.h
+HDR = csrc/engine.hpp csrc/lbfgsb.hpp csrc/dag_plan.hpp csrc/dag_kernel.inc.hpp csrc/fastmath.hpp include/hbegp.h
 
 all: $(LIB)
 

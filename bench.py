@@ -39,6 +39,14 @@ N_RESTARTS = 2
 M_CANDIDATES = 1600
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries the one JSON line): a silent multi-minute run looks hung to a driver."""
+    print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -65,11 +73,13 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
     s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
     ncores = os.cpu_count()
     t_evals = []
+    log(f"cpu baseline: {reps} full-size evaluations of the numpy/LAPACK port on 1 thread")
     with threadpool_limits(limits=1):
         for _ in range(reps):
             t0 = time.perf_counter()
             res = O.lml_with_gradient(w["X"], w["y"], s2, c, ell, 2.5)
             t_evals.append(time.perf_counter() - t0)
+            log(f"  evaluation {len(t_evals)}: {t_evals[-1]:.2f} s")
         t0 = time.perf_counter()
         O.predict(Xs, w["X"], res["alpha"], res["k_inv"], c, ell, 2.5)
         t_pred = time.perf_counter() - t0
@@ -89,6 +99,7 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
         "cpu_model": _cpu_model(),
     }
     # best effort: the same port with every host core (LAPACK threads; the tensor passes stay numpy's)
+    log("cpu baseline: the same port on all cores")
     t0 = time.perf_counter()
     O.lml_with_gradient(w["X"], w["y"], s2, c, ell, 2.5)
     t_all = time.perf_counter() - t0
@@ -98,6 +109,7 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
     from scipy.linalg import lapack
 
     Kc = res["kernel_matrix"].copy()
+    log("cpu baseline: LAPACK dpotrf + dpotri, all cores")
     t0 = time.perf_counter()
     ch, _ = lapack.dpotrf(Kc, lower=1)
     lapack.dpotri(ch, lower=1)
@@ -111,6 +123,7 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
         from oracle import c_oracle as CO
 
         ns = 1024
+        log("cpu baseline: plain-C restatement, n=1024 sample x3")
         ws = synth.make_workload("M", n=ns)
         ts = []
         for _ in range(3):
@@ -129,13 +142,15 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
 
         Kt = torch.from_numpy(res["kernel_matrix"].copy())
         tt = {}
-        for nthreads in (1, ncores):
+        many = min(ncores, 16)  # torch.cholesky_inverse with 256 threads took 389 s on the GPU box's EPYC 9575F (1.7 s on one)
+        for nthreads in (1, many):
+            log(f"cpu baseline: torch cholesky + cholesky_inverse, {nthreads} thread(s)")
             torch.set_num_threads(nthreads)
             t0 = time.perf_counter()
             L = torch.linalg.cholesky(Kt)
             torch.cholesky_inverse(L)
             tt[nthreads] = time.perf_counter() - t0
-        out["torch_cholesky_plus_inverse_s"] = {"1_thread": tt[1], f"{ncores}_threads": tt[ncores]}
+        out["torch_cholesky_plus_inverse_s"] = {"1_thread": tt[1], f"{many}_threads": tt[many]}
     except Exception as e:
         out["torch_cholesky_plus_inverse_s"] = {"error": str(e)}
     return out
@@ -378,6 +393,7 @@ def main():
         fk.release()
         return mean, var
 
+    log(f"{args.warmup} warm-up + {args.steps} timed fit+predict steps")
     for _ in range(args.warmup):
         step()
     D.barrier(dist)
@@ -386,11 +402,13 @@ def main():
         step()
     D.barrier(dist)
     elapsed = D.max_over_ranks(dist, time.perf_counter() - t0)
+    log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms per step")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed  # whole-job fit+predict per second
         nslots = 1 + N_RESTARTS
+        log("roofline: kernel times with all slots evaluating at once")
         roofline = roofline_block(gpr, ctx, X, y, theta, nslots, ms_per_step, fit_stats.get("n_evals", 0), 2.0 * M_CANDIDATES * n * n,
                                   pmc_ok=args.n is None)
         out = {
@@ -418,6 +436,7 @@ def main():
             "roofline": roofline,
         }
         # the same fit with the optimiser's own stopping rule (not timed above): evaluations it actually needs
+        log("side lines: converged fit, f32, small n")
         t0 = time.perf_counter()
         fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, nu=2.5, ctx=ctx, maxeval=EVALS_PER_RUN)
         t_conv = time.perf_counter() - t0
@@ -444,6 +463,7 @@ def main():
                 Xd, yd = ww["X"].astype(dtype), ww["y"].astype(dtype)
                 st = synth.restart_points(ww["name"], ww["lo"], ww["hi"], N_RESTARTS)
                 best = None
+                log(f"  fit rate {ww['name']} n={ww['n']} {np.dtype(dtype).name}")
                 for _ in range(reps + 1):  # first one warms the plan cache / pools
                     t0 = time.perf_counter()
                     f = gpr.FittedKernel.new(Xd, yd, ww["theta0"], ww["lo"], ww["hi"], st, nu=2.5, ctx=ctx, maxeval=EVALS_PER_RUN, fixed_work=True)
@@ -464,6 +484,7 @@ def main():
         try:
             small = {}
             for ns in (256, 512, 1024):
+                log(f"  small n: {ns}")
                 wn = synth.make_workload("M", n=ns)
                 stn = synth.restart_points("M", wn["lo"], wn["hi"], N_RESTARTS)
                 best = None

@@ -40,12 +40,17 @@ struct DagGeom {
 };
 
 constexpr int DAG_LDS_CTL_OFF = (int)((LeafGeom<double>::LDS_BYTES + 15) / 16 * 16);
-constexpr int DAG_LDS_BYTES = DAG_LDS_CTL_OFF + 128;
+constexpr int DAG_LDS_BYTES = DAG_LDS_CTL_OFF + 128;  // two control blocks of 16 dwords
 static_assert(DAG_LDS_BYTES <= 163840, "the diagonal block and the control words must fit the CU's LDS");
 
-template <typename T, int TA, int TB>
+// pull / fetch: the task loop's hooks for claiming the NEXT queue entry late in this tile's life -- pull() (thread 0: the
+// atomic on the queue head) once no operand load is left to issue, fetch() (wave 0: the entry's descriptor) before the last
+// stage, so that both round trips hide under the last MFMA stages and the entry is claimed only ~2 us before this workgroup is
+// free (claiming it a whole task earlier parks the chain's tasks behind bulk tiles: measured 2.05 -> 3.06 ms per evaluation).
+template <typename T, int TA, int TB, typename PullFn, typename FetchFn>
 __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int kbeg, int kend, T* __restrict__ W1,
-                                              T* __restrict__ W2, T* __restrict__ W3, T* __restrict__ Kinv, int ld, char* smem_raw) {
+                                              T* __restrict__ W2, T* __restrict__ W3, T* __restrict__ Kinv, int ld, char* smem_raw,
+                                              PullFn pull, FetchFn fetch) {
   using C = Cfg<T>;
   using G = DagGeom<T, TA, TB>;
   using vec_t = typename C::vec_t;
@@ -246,9 +251,19 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
       stage(1, true, ra1, rb1, true, ra0, rb0, true);
     }
     const int left = nstages - s;  // 1..3
+    if (left <= 2) pull();
+    if (left == 1) fetch();
     stage(0, left > 2, ra0, rb0, left > 1, ra1, rb1, left > 1);
+    if (left > 2) pull();
+    if (left == 2) fetch();
     if (left > 1) stage(1, false, ra1, rb1, left > 2, ra0, rb0, left > 2);
-    if (left > 2) stage(0, false, ra0, rb0, false, ra1, rb1, false);
+    if (left > 2) {
+      fetch();
+      stage(0, false, ra0, rb0, false, ra1, rb1, false);
+    }
+  } else {
+    pull();
+    fetch();
   }
 
   // epilogue: write-through stores (read by other workgroups of this launch)
@@ -328,8 +343,7 @@ __device__ __forceinline__ void dag_kmat_tile(const DagLaunch& g, int row0, int 
       const int gj = j0 + tx * 4 + c;
       T v;
       if (gi < n && gj < n) {
-        v = amp * matern_map<T>(sqrt(acc[r][c]), nu2);
-        if (gi == gj) v += noise;
+        v = kmat_entry<T>(acc[r][c], nu2, amp, noise, gi == gj);
       } else {
         v = (gi == gj) ? T(1) : T(0);
       }
@@ -462,78 +476,101 @@ __device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* 
 }
 #endif
 
+// The task loop.  A workgroup claims its next queue entry and fetches its descriptor under the last MFMA stages of the task it
+// runs (dag_gemm_tile's pull / fetch hooks).  Between two tasks the hand-off then costs only what cannot overlap:
+//   epilogue stores issued -> [wave 0: ONE look at the NEXT task's counters, in flight together with the stores' drain]
+//   -> every wave: s_waitcnt vmcnt(0) -> [wave 0: next task ready? then acquire (buffer_inv sc1) and stage its descriptor]
+//   -> barrier -> lanes 0-2 bump this task's counters -> the next task starts at once.
+// Only when that early look fails (typically: the next task waits for THIS task's counter) does wave 0 spin on the counters
+// behind the barrier and a second barrier follows -- round 2 did that for every task, plus a descriptor fetch in between
+// (0.8 us look + 0.5 us fetch + a barrier per task, of 4.4 us fixed cost).  Two LDS control blocks alternate so that the next
+// task can be staged while the current one's is still being read.
+//   ctl block (16 dwords): [0] task index, [1] 0 run / 1 skip / 2 leave, [2] 1 = staged by the early look, [4..15] the task
 template <typename T, int MODE>
 __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
   extern __shared__ __align__(16) char smem_raw[];
-  int* ctl = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);  // [0] task index, [1] 0 run / 1 skip / 2 leave, [4..15] the task
+  int* ctl_base = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);
   const int t = threadIdx.x;
   T* W1 = static_cast<T*>(g.W1);
   T* W2 = static_cast<T*>(g.W2);
   constexpr int TASK_DW = (int)(sizeof(DagTask) / 4);
-  int next = 0;  // thread 0: index of the task pulled for the next round
-  int pre = 0;   // wave 0, lanes < TASK_DW: that task's descriptor, fetched while the previous task's results were published
-  if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  static_assert(DAG_MAXWAIT == 4 && offsetof(DagTask, nwait) == 20 && offsetof(DagTask, wcnt) == 28 && offsetof(DagTask, wval) == 36,
+                "DagTask dword layout: nwait = low half of dword 5, wcnt = dwords 7-8, wval = dwords 9-10");
+  // wave 0, one look at a task's counters and at the evaluation's flag: ONE round trip (lane w reads counter w, lane 8 the flag).
+  // desc: the task's descriptor, dword t in lane t.  Returns through *inf the flag, and whether every counter is there.
+  auto look_issue = [&](int desc, int* cnt_out, int* need_out, int* inf_out) {
+    const unsigned d5 = (unsigned)__builtin_amdgcn_readlane(desc, 5), d7 = (unsigned)__builtin_amdgcn_readlane(desc, 7);
+    const unsigned d8 = (unsigned)__builtin_amdgcn_readlane(desc, 8), d9 = (unsigned)__builtin_amdgcn_readlane(desc, 9);
+    const unsigned d10 = (unsigned)__builtin_amdgcn_readlane(desc, 10);
+    const int nw = (int)(d5 & 0xffffu);
+    const unsigned wc2 = (t & 2) ? d8 : d7, wv2 = (t & 2) ? d10 : d9;
+    const int my_wcnt = (int)((t & 1) ? wc2 >> 16 : wc2 & 0xffffu), my_wval = (int)((t & 1) ? wv2 >> 16 : wv2 & 0xffffu);
+    int c = 0x7fffffff, need = 0, inf = 0;
+    if (t < nw) {
+      c = __hip_atomic_load(g.ctrl + DAG_CTRL_WORDS + my_wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      need = my_wval;
+    }
+    if (t == 8) inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *cnt_out = c; *need_out = need; *inf_out = inf;
+  };
+
+  int nxt = 0;    // thread 0: queue index of the NEXT task, claimed late in the current task's life (pull hook)
+  int desc = 0;   // wave 0, lanes < TASK_DW: descriptor of the task being staged (dword t in lane t)
+  int cur_idx = 0;  // wave 0 (uniform): its queue index
+  if (t == 0) cur_idx = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (t < 64) {
-    const int idx0 = __builtin_amdgcn_readfirstlane(next);
-    if (idx0 < g.ntasks && t < TASK_DW) pre = reinterpret_cast<const int*>(g.tasks + idx0)[t];
+    cur_idx = __builtin_amdgcn_readfirstlane(cur_idx);
+    if (cur_idx < g.ntasks && t < TASK_DW) desc = reinterpret_cast<const int*>(g.tasks + cur_idx)[t];
   }
+  int par = 0;          // control block of the task being staged / run
+  bool staged = false;  // uniform: the early look of the previous round has staged this task already
   for (;;) {
-    if (t < 64) {
-      // wave 0: stage the task descriptor in LDS (one load instruction), then its lanes wait for the task's dependencies
-      const int idx = __builtin_amdgcn_readfirstlane(next);
-      int status = idx >= g.ntasks ? 2 : 0;
-      if (g.trace && t == 0 && status == 0) g.trace[(size_t)idx * 5 + 0] = __builtin_amdgcn_s_memrealtime();
-      if (status == 0) {
-        if (t < TASK_DW) ctl[4 + t] = pre;  // for the other waves, which decode it behind the barrier below
-        // this wave decodes its wait list from the registers the descriptor arrived in (lane t holds dword t): nothing is read
-        // back from the LDS through another type before a barrier
-        const unsigned d5 = (unsigned)__builtin_amdgcn_readlane(pre, 5), d7 = (unsigned)__builtin_amdgcn_readlane(pre, 7);
-        const unsigned d8 = (unsigned)__builtin_amdgcn_readlane(pre, 8), d9 = (unsigned)__builtin_amdgcn_readlane(pre, 9);
-        const unsigned d10 = (unsigned)__builtin_amdgcn_readlane(pre, 10);
-        const int nw = (int)(d5 & 0xffffu);
-        const unsigned wc2 = (t & 2) ? d8 : d7, wv2 = (t & 2) ? d10 : d9;
-        const int my_wcnt = (int)((t & 1) ? wc2 >> 16 : wc2 & 0xffffu), my_wval = (int)((t & 1) ? wv2 >> 16 : wv2 & 0xffffu);
-        static_assert(DAG_MAXWAIT == 4 && offsetof(DagTask, nwait) == 20 && offsetof(DagTask, wcnt) == 28 && offsetof(DagTask, wval) == 36,
-                      "DagTask dword layout: nwait = low half of dword 5, wcnt = dwords 7-8, wval = dwords 9-10");
-        // every look is ONE round trip: lane w reads counter w, lane 8 the evaluation's flag (a flag raised in this very
-        // instant may be missed once: the task then computes on data nobody will use, the next task sees it).  Bounded
-        // g.wait_ticks of the 100 MHz clock (host: at least 2 s, more for long plans), then the task is recorded, the flag set and
-        // every workgroup drains out.
-        int inf = 0;
-        unsigned long long t0 = 0;
-        for (unsigned spins = 0;; ++spins) {
-          bool ok = true;
-          if (t < nw) ok = __hip_atomic_load(g.ctrl + DAG_CTRL_WORDS + my_wcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= my_wval;
-          if (t == 8) inf = __hip_atomic_load(g.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const bool all_ok = __ballot(!ok) == 0ull;
-          inf = __shfl(inf, 8, 64);
-          if (all_ok || inf < 0) break;
-          if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
-          __builtin_amdgcn_s_sleep(1);
-          if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > g.wait_ticks) {
-            if (t == 0) {
-              int expected = 0;
-              __hip_atomic_compare_exchange_strong(g.ctrl + 1, &expected, idx + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(g.info, DAG_INFO_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int* ctl = ctl_base + 16 * par;
+    if (!staged) {
+      if (t < 64) {
+        // wave 0 waits for the task's dependencies: every look is one round trip; bounded (g.wait_ticks of the 100 MHz clock,
+        // then the task is recorded, the flag set and every workgroup drains out).  A flag raised in this very instant may be
+        // missed once: the task then computes on data nobody will use, the next task sees it.
+        int status = cur_idx >= g.ntasks ? 2 : 0;
+        if (g.trace && t == 0 && status == 0) g.trace[(size_t)cur_idx * 5 + 0] = __builtin_amdgcn_s_memrealtime();
+        if (status == 0) {
+          int inf = 0;
+          unsigned long long t0 = 0;
+          for (unsigned spins = 0;; ++spins) {
+            int c, need;
+            look_issue(desc, &c, &need, &inf);
+            const bool all_ok = __ballot(c < need) == 0ull;
+            inf = __shfl(inf, 8, 64);
+            if (all_ok || inf < 0) break;
+            if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > g.wait_ticks) {
+              if (t == 0) {
+                int expected = 0;
+                __hip_atomic_compare_exchange_strong(g.ctrl + 1, &expected, cur_idx + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g.info, DAG_INFO_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+              inf = DAG_INFO_TIMEOUT;
+              break;
             }
-            inf = DAG_INFO_TIMEOUT;
-            break;
+          }
+          if (inf < 0) status = 2;
+          if (status == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines: operands were written by other CUs
+            status = inf > 0 ? 1 : 0;
           }
         }
-        if (inf < 0) status = 2;
-        if (status == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines: operands were written by other CUs
-          status = inf < 0 ? 2 : (inf > 0 ? 1 : 0);
+        if (t < TASK_DW) ctl[4 + t] = desc;
+        if (t == 0) {
+          ctl[0] = cur_idx;
+          ctl[1] = status;
+          ctl[2] = 0;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the barrier below must not open before the invalidate is complete
+          if (g.trace && status != 2) g.trace[(size_t)cur_idx * 5 + 1] = __builtin_amdgcn_s_memrealtime();
         }
       }
-      if (t == 0) {
-        ctl[0] = idx;
-        ctl[1] = status;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the barrier below must not open before the invalidate is complete
-        if (g.trace && status != 2) g.trace[(size_t)idx * 5 + 1] = __builtin_amdgcn_s_memrealtime();
-      }
+      __syncthreads();
     }
-    __syncthreads();
     const int status = __builtin_amdgcn_readfirstlane(ctl[1]);
     if (status == 2) break;
     // the task, as uniform (scalar) values: dword layout of DagTask
@@ -543,15 +580,31 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
     const int kbeg = __builtin_amdgcn_readfirstlane(ctl[7]), kend = __builtin_amdgcn_readfirstlane(ctl[8]);
     const int sig0 = (__builtin_amdgcn_readfirstlane(ctl[9]) >> 16) & 0xffff, sig12 = __builtin_amdgcn_readfirstlane(ctl[10]);
     const int sig1 = sig12 & 0xffff, sig2 = (sig12 >> 16) & 0xffff;
+    const int this_idx = __builtin_amdgcn_readfirstlane(ctl[0]);
+    // hooks: claim the next queue entry (thread 0) and fetch its descriptor (wave 0); a tile task calls them late in its
+    // pipeline, everything else right after its work
+    int ndesc = 0, nidx = 0;
+    bool pulled = false, fetched = false;
+    auto pull = [&]() {
+      if (t == 0) nxt = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pulled = true;
+    };
+    auto fetch = [&]() {
+      if (t < 64) {
+        nidx = __builtin_amdgcn_readfirstlane(nxt);
+        if (nidx < g.ntasks && t < TASK_DW) ndesc = reinterpret_cast<const int*>(g.tasks + nidx)[t];
+      }
+      fetched = true;
+    };
     if (status == 0) {
       if (kind == DAG_LEAF) {
         dag_leaf_task<T>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, smem_raw);
       } else if ((flags & DAGF_CKINV) && g.Kinv == nullptr) {
         // factorisation-only launch: the K^-1 tiles are not wanted
       } else if (kind == DAG_GEMM_128x64) {
-        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw);
+        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch);
       } else if (kind == DAG_GEMM_64x64) {
-        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw);
+        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch);
       } else if constexpr (MODE == DAG_MODE_FULL) {
         if (kind == DAG_KMAT) {
           dag_kmat_tile<T>(g, row0, col0, W1, smem_raw);
@@ -566,15 +619,42 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
         }
       }
     }
-    const int cur_idx = __builtin_amdgcn_readfirstlane(ctl[0]);
-    if (g.trace && t == 0) g.trace[(size_t)cur_idx * 5 + 2] = __builtin_amdgcn_s_memrealtime();
-    // pull the next task while this one's stores drain (the workgroup still runs its tasks in queue order)
-    if (t == 0) next = __hip_atomic_fetch_add(g.ctrl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // publish: every wave drains its write-through stores, then lanes of ONE wave bump the counters
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t < 64) {  // the next descriptor travels while the counters are bumped (the task array is read-only)
-      const int nidx = __builtin_amdgcn_readfirstlane(next);
-      if (nidx < g.ntasks && t < TASK_DW) pre = reinterpret_cast<const int*>(g.tasks + nidx)[t];
+    if (!pulled) pull();
+    if (!fetched) fetch();
+    if (g.trace && t == 0) g.trace[(size_t)this_idx * 5 + 2] = __builtin_amdgcn_s_memrealtime();
+    // ---- hand-off.  Wave 0 looks at the next task's counters while this task's write-through stores drain.
+    int* nctl = ctl_base + 16 * (par ^ 1);
+    int look_c = 0, look_need = 0, look_inf = 0;
+    const bool have_next = t < 64 && nidx < g.ntasks;  // wave-uniform
+    if (have_next) look_issue(ndesc, &look_c, &look_need, &look_inf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores are in the L2 / memory; wave 0: the look has returned
+    if (t < 64) {
+      int nstatus = 2, early = 1;  // no next entry: the workgroup leaves after this task
+      if (have_next) {
+        const bool all_ok = __ballot(look_c < look_need) == 0ull;
+        const int inf = __shfl(look_inf, 8, 64);
+        if (inf < 0) {
+          nstatus = 2;
+        } else if (all_ok) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          nstatus = inf > 0 ? 1 : 0;
+          if (g.trace && t == 0) g.trace[(size_t)nidx * 5 + 0] = __builtin_amdgcn_s_memrealtime();
+        } else {
+          early = 0;  // wait behind the barrier (the usual case: the next task needs what this one is about to publish)
+        }
+      }
+      if (early) {
+        if (t < TASK_DW) nctl[4 + t] = ndesc;
+        if (t == 0) {
+          nctl[0] = nidx;
+          nctl[1] = nstatus;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate is complete before the barrier opens
+          if (g.trace && nstatus == 0) g.trace[(size_t)nidx * 5 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+      }
+      if (t == 0) nctl[2] = early;
+      desc = ndesc;
+      cur_idx = nidx;
     }
     __syncthreads();
     {
@@ -582,13 +662,15 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
       if (t < DAG_MAXSIG && mysig != DAG_NOSIG)
         __hip_atomic_fetch_add(g.ctrl + DAG_CTRL_WORDS + mysig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (g.trace && t == 0) {
-        g.trace[(size_t)cur_idx * 5 + 3] = __builtin_amdgcn_s_memrealtime();
+        g.trace[(size_t)this_idx * 5 + 3] = __builtin_amdgcn_s_memrealtime();
         unsigned xcc = 0, hwid = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g.trace[(size_t)cur_idx * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+        g.trace[(size_t)this_idx * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
       }
     }
+    par ^= 1;
+    staged = __builtin_amdgcn_readfirstlane(ctl_base[16 * par + 2]) != 0;
   }
 }
 

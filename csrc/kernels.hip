@@ -22,6 +22,7 @@
 #include <string>
 
 #include "engine.hpp"
+#include "fastmath.hpp"
 
 namespace hbegp {
 
@@ -799,19 +800,28 @@ template void launch_leaf<float>(float*, float*, int, int, float*, int*, hipStre
 // (matern_kernel.rs:79 is unimplemented! for other nu); its oracle is sklearn's RBF (tests/golden/*_rbf.npz).
 template <typename T>
 __device__ __forceinline__ T matern_map(T r, int nu2) {
-  if (nu2 == 0) return exp(T(-0.5) * r * r);
-  if (nu2 == 1) return exp(-r);
+#pragma clang fp contract(off)
+  if (nu2 == 0) return exp_nonpos(T(-0.5) * r * r);
+  if (nu2 == 1) return exp_nonpos(-r);
   if (nu2 == 3) {
     const T k = r * T(1.7320508075688772);
-    return (k + T(1)) * exp(-k);
+    return (k + T(1)) * exp_nonpos(-k);
   }
   const T k = r * T(2.23606797749979);
-  return (T(1) + k + k * k / T(3)) * exp(-k);
+  return __builtin_fma(k * k, T(1.0 / 3.0), T(1) + k) * exp_nonpos(-k);
+}
+// one entry of K from the squared scaled distance (matern_kernel.rs:37-81 x constant_kernel.rs x + noise on the diagonal, lml.rs:44)
+template <typename T>
+__device__ __forceinline__ T kmat_entry(T dist2, int nu2, T amp, T noise, bool diag) {
+#pragma clang fp contract(off)
+  const T v = amp * matern_map<T>(sqrt_nonneg(dist2), nu2);  // product_kernel.rs:37 (k1 * k2)
+  return diag ? v + noise : v;
 }
 
-// 64x64 tile per workgroup; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.
-template <typename T>
-__global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int n, int d, int np, int nu2,
+// 64x64 tile per workgroup; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.  NU2: the Matern order at
+// compile time (no branch per entry); tiles that lie wholly inside the n x n matrix skip the per-entry bounds tests.
+template <typename T, int NU2>
+__global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int n, int d, int np,
                                                    const EvalParams* __restrict__ P, T* __restrict__ W,
                                                    const int* info) {
   if (*info != 0) return;
@@ -850,25 +860,30 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
       }
   }
   const T amp = (T)P->amp, noise = (T)P->noise;
+  typedef T vec4 __attribute__((ext_vector_type(4)));
+  if (i0 + 64 <= n && j0 + 64 <= n) {
+    const bool dtile = li == lj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gi = i0 + ty + 16 * r;
+      vec4 out;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[c] = kmat_entry<T>(acc[r][c], NU2, amp, noise, dtile && gi == j0 + tx * 4 + c);
+      *reinterpret_cast<vec4*>(W + (size_t)gi * np + j0 + tx * 4) = out;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int gi = i0 + ty + 16 * r;
-    T out[4];
+    vec4 out;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int gj = j0 + tx * 4 + c;
-      T v;
-      if (gi < n && gj < n) {
-        v = amp * matern_map<T>(sqrt(acc[r][c]), nu2);  // product_kernel.rs:37 (k1 * k2)
-        if (gi == gj) v += noise;                        // lml.rs:44
-      } else {
-        v = (gi == gj) ? T(1) : T(0);                    // identity padding
-      }
-      out[c] = v;
+      const T v = kmat_entry<T>(acc[r][c], NU2, amp, noise, gi == gj);
+      out[c] = (gi < n && gj < n) ? v : ((gi == gj) ? T(1) : T(0));  // identity padding
     }
-    T* p = W + (size_t)gi * np + j0 + tx * 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) p[c] = out[c];
+    *reinterpret_cast<vec4*>(W + (size_t)gi * np + j0 + tx * 4) = out;
   }
 }
 
@@ -876,7 +891,13 @@ template <typename T>
 void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s) {
   const int nt = np / 64;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
-  hipLaunchKernelGGL((kmat_kernel<T>), dim3(nt * (nt + 1) / 2), dim3(256), lds, s, X, n, d, np, nu2, P, W, info);
+  const dim3 grid(nt * (nt + 1) / 2), block(256);
+  switch (nu2) {
+    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info); break;
+    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info); break;
+    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info); break;
+    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info); break;
+  }
 }
 template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t);
 template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t);
@@ -1000,8 +1021,8 @@ template void launch_alpha_lml<float>(const float*, int, int, const float*, cons
 // =================================================================================================================
 constexpr int GT_CHUNK = 8;  // length-scale parameters accumulated per register pass
 
-template <typename T>
-__global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np, int nu2,
+template <typename T, int NU2>
+__global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np,
                                                         const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
                                                         const T* __restrict__ alpha, double* __restrict__ part,
                                                         const int* info) {
@@ -1052,42 +1073,66 @@ __global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X,
           dsum[r][c] += df * df * il2;
         }
     }
+    // Matern value km and gradient factor gr of one entry: dK/dlog(ell_k) = c * gr * d_k (matern_kernel.rs:102-131)
+    auto km_gr = [&](T ds, T* km, T* gr) {
+#pragma clang fp contract(off)
+      if (NU2 == 5) {
+        const T tt = sqrt_nonneg(ds * T(5));
+        const T e = exp_nonpos(-tt);
+        *km = __builtin_fma(tt * tt, T(1.0 / 3.0), T(1) + tt) * e;
+        *gr = T(5.0 / 3.0) * (tt + T(1)) * e;  // matern_kernel.rs:119-131
+      } else if (NU2 == 3) {
+        const T tt = sqrt_nonneg(ds * T(3));
+        const T e = exp_nonpos(-tt);
+        *km = (tt + T(1)) * e;
+        *gr = T(3) * e;  // matern_kernel.rs:112-118
+      } else if (NU2 == 0) {
+        *km = exp_nonpos(T(-0.5) * ds);  // squared exponential: dK/dlog(ell_k) = K * d_k
+        *gr = *km;
+      } else {
+        const T rr = sqrt_nonneg(ds);
+        *km = exp_nonpos(-rr);
+        *gr = (rr > T(0)) ? *km / rr : T(0);  // matern_kernel.rs:102-111 (non-finite -> 0)
+      }
+    };
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    if (li > lj && i0 + 64 <= n) {
+      // a tile strictly below the diagonal and wholly inside the matrix: every entry counts twice, no bounds tests
+      const vec4 aj = *reinterpret_cast<const vec4*>(alpha + j0 + tx * 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gi = i0 + ty + 16 * r;
-      const T ai = (gi < n) ? alpha[gi] : T(0);
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + ty + 16 * r;
+        const T ai = alpha[gi];
+        const vec4 kv = *reinterpret_cast<const vec4*>(Kinv + (size_t)gi * np + j0 + tx * 4);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int gj = j0 + tx * 4 + c;
-        T cf = T(0);
-        if (gi < n && gj <= gi) {
-          const T w = ai * alpha[gj] - Kinv[(size_t)gi * np + gj];  // lml.rs:62 (tmp)
-          const T wgt = (gi == gj) ? T(1) : T(2);
-          const T ds = dsum[r][c];
-          T km, gr;  // Matern value and gradient factor g(r) with dK/dlog(ell_k) = c * g * d_k
-          if (nu2 == 5) {
-            const T tt = sqrt(ds * T(5));
-            const T e = exp(-tt);
-            km = (T(1) + tt + tt * tt / T(3)) * e;
-            gr = T(5.0 / 3.0) * (tt + T(1)) * e;  // matern_kernel.rs:119-131
-          } else if (nu2 == 3) {
-            const T tt = sqrt(ds * T(3));
-            const T e = exp(-tt);
-            km = (tt + T(1)) * e;
-            gr = T(3) * e;  // matern_kernel.rs:112-118
-          } else if (nu2 == 0) {
-            km = exp(T(-0.5) * ds);  // squared exponential: dK/dlog(ell_k) = K * d_k
-            gr = km;
-          } else {
-            const T rr = sqrt(ds);
-            km = exp(-rr);
-            gr = (rr > T(0)) ? km / rr : T(0);  // matern_kernel.rs:102-111 (non-finite -> 0)
-          }
-          if (gi == gj) g_noise += (double)(w * noise);      // noise gradient = eye * noise (lml.rs:41)
-          g_amp += (double)(wgt * w * (amp * km));            // constant_kernel.rs:31-38 x K_matern
-          cf = wgt * w * amp * gr;
+        for (int c = 0; c < 4; ++c) {
+          const T w = ai * aj[c] - kv[c];  // lml.rs:62 (tmp)
+          T km, gr;
+          km_gr(dsum[r][c], &km, &gr);
+          g_amp += (double)(T(2) * w * (amp * km));  // constant_kernel.rs:31-38 x K_matern
+          coef[r][c] = T(2) * w * amp * gr;
         }
-        coef[r][c] = cf;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + ty + 16 * r;
+        const T ai = (gi < n) ? alpha[gi] : T(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gj = j0 + tx * 4 + c;
+          T cf = T(0);
+          if (gi < n && gj <= gi) {
+            const T w = ai * alpha[gj] - Kinv[(size_t)gi * np + gj];  // lml.rs:62 (tmp)
+            const T wgt = (gi == gj) ? T(1) : T(2);
+            T km, gr;
+            km_gr(dsum[r][c], &km, &gr);
+            if (gi == gj) g_noise += (double)(w * noise);      // noise gradient = eye * noise (lml.rs:41)
+            g_amp += (double)(wgt * w * (amp * km));            // constant_kernel.rs:31-38 x K_matern
+            cf = wgt * w * amp * gr;
+          }
+          coef[r][c] = cf;
+        }
       }
     }
   }
@@ -1164,7 +1209,13 @@ void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParam
   const int nt = np / 64;
   const int nblocks = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
-  hipLaunchKernelGGL((gradtrace_kernel<T>), dim3(nblocks), dim3(256), lds, s, X, n, d, np, nu2, P, Kinv, alpha, part, info);
+  const dim3 grid(nblocks), block(256);
+  switch (nu2) {
+    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
+    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
+    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
+    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
+  }
   hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, nblocks, d + 2, out, info);
 }
 template void launch_gradtrace<double>(const double*, int, int, int, int, const EvalParams*, const double*, const double*,
@@ -1261,7 +1312,7 @@ __global__ void __launch_bounds__(256) kstar_kernel(const T* __restrict__ Xs, in
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int gj = j0 + tx * 4 + c;
-      p[c] = (gi < m && gj < n) ? amp * matern_map<T>(sqrt(acc[r][c]), nu2) : T(0);
+      p[c] = (gi < m && gj < n) ? kmat_entry<T>(acc[r][c], nu2, amp, T(0), false) : T(0);
     }
   }
 }
@@ -1347,7 +1398,7 @@ __global__ void __launch_bounds__(256) kstar_small_kernel(const T* __restrict__ 
         const T df = Xs[(size_t)q * d + k] / ell - X[(size_t)j * d + k] / ell;
         acc += df * df;
       }
-      v = amp * matern_map<T>(sqrt(acc), nu2);
+      v = kmat_entry<T>(acc, nu2, amp, T(0), false);
     }
     if (j < np) Ks[(size_t)q * np + j] = v;
     const double part = block_sum((j < n) ? (double)v * (double)alpha[j] : 0.0, red);

@@ -101,7 +101,10 @@ def test_task_queue_drains_when_not_positive_definite(rl, monkeypatch):
     monkeypatch.setenv("HBEGP_DAG_RL", str(rl))
     rng = np.random.default_rng(5)
     X = rng.random((400, 3))
-    X[300] = X[10]  # duplicate rows + vanishing noise: block 2 fails, blocks 0-1 succeed
+    # Copies of one row + vanishing noise: K is exactly singular, so blocks 0-1 succeed and block 2 (rows 256..) fails.  MANY
+    # copies, not one: a single copy's pivot is 0 up to rounding and lands on either side (it did, when the kernel matrix's
+    # exp/sqrt changed by an ulp); each further copy is another draw, 144 of them never all come out positive.
+    X[256:] = X[10]
     y = rng.random(400)
     prob = gpr.Problem(X, y)
     assert prob.lml_with_gradient(np.array([math.log(1e-300), 0.0, 0.0, 0.0, 0.0])) is None

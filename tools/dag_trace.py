@@ -27,3 +27,21 @@ lr, lp = ready[lm][order], pub[lm][order]
 gaps = lr[1:] - lp[:-1]
 print("leaf chain: leaf busy median %.1f us; gap leaf(k) published -> leaf(k+1) ready: median %.1f max %.1f sum %.0f us" % (np.median(lp - lr), np.median(gaps), gaps.max(), gaps.sum()))
 print("gaps:", " ".join(f"{g:.0f}" for g in gaps))
+
+# hand-off between consecutive tasks of one workgroup (a workgroup stays on its CU): end of compute of task a -> task b running
+cu = a[:, 10] * (1 << 32) + (a[:, 11] & 0xffffff00)
+gaps_all, gaps_early, gaps_spin, n_early = [], [], [], 0
+for c in set(cu):
+    m = np.nonzero(cu == c)[0]
+    m = m[np.argsort(ready[m])]
+    for x, y in zip(m[:-1], m[1:]):
+        gap = ready[y] - comp[x]
+        early = pulled[y] < pub[x]
+        gaps_all.append(gap)
+        (gaps_early if early else gaps_spin).append(gap)
+ga, ge, gs = np.array(gaps_all), np.array(gaps_early), np.array(gaps_spin)
+print(f"hand-offs: {len(ga)}; computed(a) -> ready(b): median {np.median(ga):.2f} us, mean {ga.mean():.2f}, sum {ga.sum():.0f} us")
+if len(ge):
+    print(f"   staged by the early look: {len(ge)} ({100.0 * len(ge) / len(ga):.0f} %), median {np.median(ge):.2f} us, mean {ge.mean():.2f}")
+if len(gs):
+    print(f"   waited behind the barrier: {len(gs)}, median {np.median(gs):.2f} us, mean {gs.mean():.2f}, of which <= 5 us: {int((gs <= 5).sum())}")
