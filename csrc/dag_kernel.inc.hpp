@@ -24,11 +24,19 @@
 // Arithmetic per output element is the same sequence of MFMA accumulations as in gemm_kernel (k ascending in steps of
 // four, operands identical), so results are bitwise equal to the launch-per-product path.
 
+// Contraction depth of one pipeline stage of the task-queue tiles, in units of Cfg<T>::BK (128 bytes of k).  Experiment (round
+// 3): f64 with 2 -> 32 elements per stage, as f32 has -- twice the MFMAs between two stage barriers (32 per wave), half as many
+// barrier bubbles per flop; the old values of a beta = 1 tile then live in registers for both tile shapes (the 128x64 stash no
+// longer fits the LDS).  Measured SLOWER: 2048-deep 128x64 tile 127.3 vs 123.3 us, fit+predict/s 1.625 vs 1.665 (same box,
+// 0 spills either way): the barrier bubble is not what costs the 9 % between the stage loop and the MFMA rate.  Stays 1.
+#ifndef DAG_F64_KMUL
+#define DAG_F64_KMUL 1
+#endif
 template <typename T, int TA, int TB>
 struct DagGeom {
   using C = Cfg<T>;
   static constexpr int NT = 512;
-  static constexpr int BK = C::BK;
+  static constexpr int BK = sizeof(T) == 8 ? DAG_F64_KMUL * C::BK : C::BK;
   static constexpr int SK = BK + 2;                    // LDS row stride, operand stored [outer][k]
   static constexpr int SMA = TA + 16, SMB = TB + 16;   // LDS row stride, operand stored [k][outer]
   static constexpr int LDSA = (TA * SK > BK * SMA) ? TA * SK : BK * SMA;
@@ -110,9 +118,10 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   // the LDS behind the stage buffers until the epilogue.  Measured on the 128-deep 128x64 update: 13.8 -> 9.9 us.
   const bool accum = (flags & DAGF_ACC) != 0;
   const bool cinit = sizeof(T) == 8 && (flags & DAGF_CINIT) != 0;  // the old values start the accumulation (engine.hpp)
-  constexpr bool PREFETCH_C = TA == 64;
+  constexpr bool PREFETCH_C = TA == 64 || (sizeof(T) == 8 && DAG_F64_KMUL > 1);
   constexpr int STASH_OFF = 2 * (G::LDSA + G::LDSB);  // in elements of T, behind [A buf0 | A buf1 | B buf0 | B buf1]
-  static_assert((size_t)(STASH_OFF + TA * TB) * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stash must fit in front of the control words");
+  static_assert(PREFETCH_C || (size_t)(STASH_OFF + TA * TB) * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stash must fit in front of the control words");
+  static_assert((size_t)STASH_OFF * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stage buffers must fit in front of the control words");
   T cold[PREFETCH_C ? TMA : 1][PREFETCH_C ? TMB : 1][4];
   if constexpr (PREFETCH_C) {
     const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
@@ -457,7 +466,7 @@ __device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
 // the pivot-row copy (LEAF_DIAG_COPY) the called build is bitwise reproducible too (0 deviations in 39,600 concurrent
 // evaluations, 5 without the copy).  Variant 2 names the workgroup's dynamic LDS itself and keeps ds_ accesses.
 #ifndef DAG_LEAF_NOINLINE
-#define DAG_LEAF_NOINLINE 0
+#define DAG_LEAF_NOINLINE 1  /* round 3: on.  Kernel body 0 spilled VGPRs (inlined: 21 f64 / 53 f32); fit+predict/s 1.690 vs 1.682 */
 #endif
 template <typename T>
 #if DAG_LEAF_NOINLINE == 2
@@ -682,6 +691,8 @@ void launch_dag(const DagLaunch& g, int nwg, hipStream_t s) {
 }
 template void launch_dag<double>(const DagLaunch&, int, hipStream_t);
 template void launch_dag<float>(const DagLaunch&, int, hipStream_t);
+
+int dag_stage_depth(bool is_f32) { return is_f32 ? DagGeom<float, 128, 64>::BK : DagGeom<double, 128, 64>::BK; }
 
 static void init_dag_kernels() {
   set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_FACTOR>), DAG_LDS_BYTES, "dag_kernel<f64>: dynamic LDS limit");

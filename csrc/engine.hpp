@@ -146,6 +146,7 @@ struct DagLaunch {
 };
 template <typename T>
 void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);
+int dag_stage_depth(bool is_f32);  // contraction elements per pipeline stage of the task-queue tiles (task ranges are whole stages)
 
 // ---- launchers (kernels.hip), T in {double, float} ------------------------------------------------------------
 template <typename T>

@@ -479,7 +479,7 @@ struct Problem : ProblemBase {
       static std::mutex cache_mu;
       static std::map<std::array<int, 12>, std::shared_ptr<const DagPlan>> cache;
       auto plan_for = [&](int nwg) {
-        std::array<int, 12> key = {np / NB, is_f32 ? 32 : 16, env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
+        std::array<int, 12> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
                                    env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                    env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1),
                                    env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66

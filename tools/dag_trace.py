@@ -17,6 +17,21 @@ for k in (2, 1, 0):
         m = (kind == k) & (depth == d)
         c, p, w = comp[m] - ready[m], pub[m] - comp[m], ready[m] - pulled[m]
         print(f"{names[k] + ' k=' + str(d):24s} {m.sum():5d} {np.median(c):9.2f} {np.median(p):9.2f} {np.median(w):9.2f} {(pub[m] - ready[m]).sum():14.0f}")
+# where the busy time exceeds the MFMA-only ideal (one CU: 128 fp64 flop per clock at 2.4 GHz = 0.307 TFLOP/s), by class
+ideal_all, busy_all = 0.0, 0.0
+rows = []
+for k in (1, 0):
+    for d in sorted(set(depth[kind == k])):
+        m = (kind == k) & (depth == d)
+        flop = (128 if k == 0 else 64) * 64 * d * 2.0
+        ideal = flop / 0.3072e6  # us
+        b = (pub[m] - ready[m])
+        rows.append((b.sum() - ideal * m.sum(), names[k], d, int(m.sum()), ideal, float(np.median(b))))
+        ideal_all += ideal * m.sum(); busy_all += b.sum()
+rows.sort(reverse=True)
+print(f"tile tasks: busy {busy_all:.0f} us, MFMA-only ideal {ideal_all:.0f} us ({100 * ideal_all / busy_all:.1f} %); largest excess by class:")
+for ex, nm, d, cnt, ideal, med in rows[:12]:
+    print(f"   {nm} k={d}: {cnt} tasks, median busy {med:.2f} us vs ideal {ideal:.2f} us, excess {ex:.0f} us")
 busy = (pub - ready).sum()
 held = (pub - pulled).sum()
 print(f"sum busy {busy:.0f} us, sum held (incl. waiting) {held:.0f} us, makespan x CUs = {pub.max() * len(set(zip(a[:,10], a[:,11] & 0xffffff00))):.0f}")
