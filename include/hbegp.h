@@ -143,7 +143,8 @@ int hbegp_fit_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, 
                   const double* lo, const double* hi, const double* starts, int n_restarts,
                   const hbegp_fit_options* opt, double* theta_best, double* lml_best, hbegp_model** model);
 
-/* One evaluation at fixed theta + K^-1 (fit.rs:33-68).  HBEGP_NOT_PD where the reference panics (fit.rs:55). */
+/* One evaluation at fixed theta + K^-1 (fit.rs:33-68).  HBEGP_NOT_PD where the reference panics (fit.rs:55).  For f64 the result is
+ * bit for bit what an evaluation of the same theta inside hbegp_fit_f64 produces (one order of operations for one theta). */
 int hbegp_extend_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, const double* theta,
                      const double* lo, const double* hi, hbegp_model** model);
 int hbegp_extend_f32(hbegp_ctx* ctx, const float* X, const float* y, int n, int d, double nu, const double* theta,
