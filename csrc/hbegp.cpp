@@ -358,12 +358,16 @@ struct Problem : ProblemBase {
   bool refine_ = false;
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
+  bool like_fit_ = false;                   // path selection of a fit (task queue from 8 blocks on) although there is one slot
   int leaf_dbg_ = 0;                        // HBEGP_LEAF_DBG: debug bits of the diagonal-block kernel (16: helper waves start late)
 
   // single_shot: the problem runs one evaluation (extend): skip the static schedule tables, every GEMM launch is ad hoc
-  Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_, bool single_shot = false) {
+  // like_fit: choose the evaluation path (launches / task queue) as a fit of this size does, whatever the slot count --
+  // `extend` then repeats the fit's own evaluation of a theta bit for bit
+  Problem(hbegp_ctx* c, const T* X, const T* y, int n_, int d_, double nu, int n_slots_, bool single_shot = false, bool like_fit = false) {
     try {
       adhoc_ = single_shot;
+      like_fit_ = like_fit;
       init(c, X, y, n_, d_, nu, n_slots_);
     } catch (...) {
       release();  // a constructor that throws never runs the destructor: give back what was allocated so far
@@ -438,7 +442,7 @@ struct Problem : ProblemBase {
     const int dag_env = env_int("HBEGP_DAG", -1);
     // measured (config M data, launches vs task queue): one evaluation alone n=1536: 0.75 / 0.78 ms, 2048: 1.05 / 1.02, 4096: 2.89 / 2.19,
     // 8192: 12.7 / 9.9; three concurrent optimiser runs (fits/s) n=512: 21.1 / 19.6, 1024: 11.35 / 11.48, 1536: 6.80 / 7.95, 4096: 1.29 / 1.58
-    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", n_slots >= 2 ? 8 : 16);
+    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", (n_slots >= 2 || like_fit_) ? 8 : 16);
     dag_ = (dag_env < 0 ? np / NB >= dag_min_blocks : dag_env != 0) && !adhoc_ && np / NB >= 2;
     if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
@@ -1580,7 +1584,12 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
                      const double* hi, hbegp_model** model_out) {
   hbegp_ctx one;
   one.devs = {ctx->devs[0]};
-  Problem<T> prob(&one, X, y, n, d, nu, 1, env_int("HBEGP_EXTEND_SCHED", 0) == 0);
+  // One order of operations for one theta: the evaluation runs the way a fit's evaluations do at this size -- through the task
+  // queue from 8 blocks on (its K^-1 split gives the undivided tiles' bits, DAGF_CINIT), as ad-hoc launches below that (a tile's
+  // arithmetic does not depend on how the launch is scheduled).
+  const int dag_env = env_int("HBEGP_DAG", -1);
+  const bool queue_like_fit = (dag_env < 0 ? round_up(n, NB) / NB >= env_int("HBEGP_DAG_MIN_BLOCKS", 8) : dag_env != 0) && round_up(n, NB) / NB >= 2;
+  Problem<T> prob(&one, X, y, n, d, nu, 1, !queue_like_fit && env_int("HBEGP_EXTEND_SCHED", 0) == 0, true);
   const int p = d + 2;
   Slot<T>& s = prob.slots[0][0];
   theta_to_params(theta, lo, hi, d, s.hP);

@@ -256,3 +256,23 @@ def test_incremental_extend_falls_back_when_the_prefix_differs():
     assert not small.extend_with(X, y).incremental
     with pytest.raises(Exception):
         prior.extend_with(X[:, :4], y)  # wrong feature count
+
+
+@pytest.mark.parametrize("n,dtype", [(700, np.float64), (1100, np.float64), (1300, np.float32)])
+def test_extend_repeats_the_fits_own_evaluation_bit_for_bit(n, dtype):
+    # One order of operations for one theta: `extend` at the fitted theta runs the evaluation the way the
+    # fit ran it (launches below 8 blocks, the task queue from there on, whose single-slot K^-1 split continues the undivided
+    # tiles' accumulation), so lml, alpha and K^-1 are the captured evaluation's, bit for bit.
+    w = synth.make_workload("M", n=n)
+    X, y = w["X"].astype(dtype), w["y"].astype(dtype)
+    starts = synth.restart_points("M", w["lo"], w["hi"], 2)
+    fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, maxeval=25, trace=True)
+    best = int(np.argmax(fk.trace["lml"]))  # the captured evaluation (first maximum, fit.rs:116-125); its theta as the optimiser passed it
+    assert fk.trace["lml"][best] == fk.lml
+    ex = gpr.FittedKernel.extend(X, y, fk.trace["theta"][best], w["lo"], w["hi"])
+    assert ex.lml == fk.lml
+    a1, k1 = fk.arrays()
+    a2, k2 = ex.arrays()
+    assert np.array_equal(a1, a2) and np.array_equal(k1, k2)
+    fk.release()
+    ex.release()
