@@ -334,6 +334,8 @@ def main():
     ap.add_argument("--workload", default="M", choices=["M", "C3"])
     ap.add_argument("--n", type=int, default=None, help="override n (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-lines", action="store_true",
+                    help="skip the f32 / small-n / converged-fit side lines (profiling runs: the kernel statistics then hold the headline workload only)")
     ap.add_argument("--dry", action="store_true", help="launcher/harness rehearsal on CPU (gloo, no GPU work): prints the line with value 0")
     args = ap.parse_args()
 
@@ -435,6 +437,13 @@ def main():
             },
             "roofline": roofline,
         }
+        if args.no_side_lines:
+            print(json.dumps(out), flush=True)
+            if dist is not None:
+                D.barrier(dist)
+                dist.destroy_process_group()
+            ctx.close()
+            return
         # the same fit with the optimiser's own stopping rule (not timed above): evaluations it actually needs
         log("side lines: converged fit, f32, small n")
         t0 = time.perf_counter()

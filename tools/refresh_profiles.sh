@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 echo "[1/7] kernel trace of bench.py (3 concurrent optimiser runs, task-queue launches)"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-side-lines --steps 3 --warmup 1 > "$OUT/bench_trace.log" 2>&1
 cp "$OUT/bench/run_kernel_stats.csv" "$OUT/${TAG}_bench_3stream_kernel_stats.csv"
 python3 "$ROOT/tools/trace_timeline.py" "$OUT/bench/run_kernel_trace.csv" > "$OUT/${TAG}_bench_3stream_timeline.txt" 2>&1 || true
 rm -rf "$OUT/bench"
