@@ -283,3 +283,48 @@ def test_handful_of_candidates_path_matches_oracle_and_batched_path(m, dtype):
     a = fk.predict(Xs[:m])
     b = fk.predict(Xs[:m])
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def _random_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        n = int(rng.integers(1, 700))
+        d = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 64]))
+        nu = [0.5, 1.5, 2.5, math.inf][int(rng.integers(0, 4))]
+        dtype = np.float32 if rng.random() < 0.25 else np.float64
+        cases.append((n, d, nu, dtype, int(rng.integers(0, 2 ** 31))))
+    return cases
+
+
+@pytest.mark.parametrize("n,d,nu,dtype,seed", _random_cases(24, 20261004))
+def test_random_shapes_against_oracle(n, d, nu, dtype, seed):
+    # A seeded sweep over what the fixed cases leave out: ragged n (1 .. 699, every padding remainder), every d class up to the
+    # 64-feature limit, all four kernels, both element types -- lml, gradient, alpha and the predictive mean / variance at a
+    # few candidates against the oracle (lml.rs:29-79, predict.rs:7-52) at the path's bar: 1e-8 (f64), 1e-4 (f32, against the
+    # f64 oracle on the same rounded inputs).
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, d)).astype(dtype)
+    y = (np.sin(3.0 * X[:, 0].astype(np.float64)) + 0.3 * rng.standard_normal(n) + 1.0).astype(dtype)
+    ell = 0.4 + 0.6 * rng.random(d) * math.sqrt(d)
+    c = 0.5 + rng.random()
+    s2 = c * (0.05 + 0.2 * rng.random())  # well-conditioned: the sweep is about shapes, not about cond(K)
+    theta = np.concatenate([[math.log(s2), math.log(c)], np.log(ell)])
+    tol = 1e-8 if dtype == np.float64 else 1e-4
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    ref = O.lml_with_gradient(X64, y64, s2, c, ell, nu)
+    prob = gpr.Problem(X, y, nu=nu)
+    lml, grad = prob.lml_with_gradient(theta)
+    alpha, kinv, _ = prob.results()
+    prob.close()
+    assert abs(lml - ref["lml"]) <= tol * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(grad, ref["grad"], rtol=0, atol=tol * max(1.0, np.abs(ref["grad"]).max()))
+    np.testing.assert_allclose(alpha, ref["alpha"], rtol=0, atol=tol * max(1.0, np.abs(ref["alpha"]).max()))
+    np.testing.assert_allclose(kinv, ref["k_inv"], rtol=0, atol=tol * max(1.0, np.abs(ref["k_inv"]).max()))
+    fk = gpr.FittedKernel.extend(X, y, theta, nu=nu)
+    Xs = rng.random((5, d)).astype(dtype)
+    mean, var, _ = fk.predict(Xs)
+    rm, rv, _ = O.predict(Xs.astype(np.float64), X64, ref["alpha"], ref["k_inv"], c, ell, nu)
+    fk.release()
+    np.testing.assert_allclose(mean, rm, rtol=0, atol=tol * max(1.0, np.abs(rm).max()))
+    np.testing.assert_allclose(var, rv, rtol=0, atol=tol * c * (10 if dtype == np.float32 else 1))
