@@ -100,3 +100,16 @@ def test_checker_rejects_broken_plans(fault, monkeypatch):
     monkeypatch.setenv("HBEGP_DAG_TEST_FAULT", fault)
     rc, info = plan(32)
     assert rc == _lib.EINVAL and info["err"], fault
+
+
+def test_plan_builder_and_optimiser_are_clean_under_sanitizers(tmp_path):
+    # host code of the hot path (csrc/dag_plan.hpp: both plans, 1..40 blocks, validator; csrc/lbfgsb.hpp: gradmin.rs:75-101 KAT)
+    # compiled with AddressSanitizer + UndefinedBehaviorSanitizer -- sanitizers run on the CPU build only
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "san_plan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(root, "csrc"),
+                           "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tools", "san_plan.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "0 problems" in out.stdout, out.stdout + out.stderr
