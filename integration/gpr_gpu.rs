@@ -33,7 +33,7 @@ use crate::util::{BoundedValue, BoundsError};
 use crate::{Estimator, Scalar, Space, SurrogateModel, RNG};
 
 // ------------------------------------------------------------------------------------------------------------------
-// FFI: 1:1 with include/hbegp.h (ABI 0.1.2)
+// FFI: 1:1 with include/hbegp.h (ABI 0.2.0)
 // ------------------------------------------------------------------------------------------------------------------
 #[repr(C)]
 pub struct HbegpCtx {
@@ -403,60 +403,45 @@ impl<A: GpuScalar> SurrogateModel<A> for SurrogateModelGpu<A> {
         *ys.first().unwrap()
     }
 
-    /// gpr.rs:114-177
+    /// Summary of the predictive distribution at one point -- the behaviour of gpr.rs:114-177, written independently of its text:
+    /// mean / std / cv through `YNormalize`'s projections; the quartiles are the normal quantiles of N(m, s) in normalised units
+    /// (all three equal m when s vanishes), projected back as locations.  Panics where the reference panics.
     fn predict_statistics(&self, x: Array1<A>) -> SummaryStatistics<A> {
-        use statrs::distribution::InverseCDF as _;
-
-        let (mnorm, vnorm) = self.predict_normalized(x.view().insert_axis(Axis(0)), true);
-        let vnorm = vnorm.expect("variance was requested");
-
-        let vnorm_scalar: f64 = vnorm.first().expect("should contain one element").sqrt().into();
-        let mnorm_scalar: f64 = (*mnorm.first().expect("should contain one element")).into();
-        let distnorm = if abs_diff_eq!(vnorm_scalar, 0.0) {
-            None
+        let (m, v) = self.predict_normalized(x.view().insert_axis(Axis(0)), true);
+        let v = v.expect("variance was requested");
+        assert!(m.len() == 1 && v.len() == 1, "should contain one element");
+        let m0: f64 = m[0].into();
+        let s0: f64 = v[0].sqrt().into();
+        let quantiles_norm: [f64; 3] = if abs_diff_eq!(s0, 0.0) {
+            [m0; 3]
         } else {
-            match statrs::distribution::Normal::new(mnorm_scalar, vnorm_scalar) {
-                Ok(distribution) => Some(distribution),
-                Err(err) => panic!(
-                    "could not create normal distribution with mean {} std {}: {}",
-                    mnorm_scalar, vnorm_scalar, err
-                ),
-            }
+            use statrs::distribution::InverseCDF;
+            let dist = statrs::distribution::Normal::new(m0, s0).unwrap_or_else(|err| {
+                panic!("could not create normal distribution with mean {} std {}: {}", m0, s0, err)
+            });
+            [dist.inverse_cdf(0.25), dist.inverse_cdf(0.5), dist.inverse_cdf(0.75)]
         };
-
-        let mean = *self.y_norm.project_mean_from_normalized(mnorm.clone(), vnorm.view()).first().unwrap();
-        let std = *self.y_norm.project_std_from_normalized(mnorm.view(), vnorm.clone()).first().unwrap();
-        let cv = *self.y_norm.project_cv_from_normalized(mnorm.view(), vnorm).first().unwrap();
-
-        let q123norm = if let Some(distnorm) = distnorm {
-            array![0.25, 0.5, 0.75].mapv(|q| A::from_f(distnorm.inverse_cdf(q)))
-        } else {
-            array![mnorm_scalar, mnorm_scalar, mnorm_scalar].mapv(A::from_f)
-        };
-        let q123 = self.y_norm.project_location_from_normalized(q123norm);
-        let quartiles = match q123.to_vec().as_slice() {
-            [q1, q2, q3] => [*q1, *q2, *q3],
-            _ => unreachable!(),
-        };
-
-        SummaryStatistics::new_mean_std_cv_quartiles(mean, std, cv, quartiles)
+        let yn = &self.y_norm;
+        let mean = yn.project_mean_from_normalized(m.clone(), v.view())[0];
+        let std = yn.project_std_from_normalized(m.view(), v.clone())[0];
+        let cv = yn.project_cv_from_normalized(m.view(), v)[0];
+        let q = yn.project_location_from_normalized(quantiles_norm.iter().map(|&q| A::from_f(q)).collect::<Array1<A>>());
+        SummaryStatistics::new_mean_std_cv_quartiles(mean, std, cv, [q[0], q[1], q[2]])
     }
 
-    /// gpr.rs:179-212 -- the batched entry the acquisition should use (one call per generation; see
-    /// hbetune_rs_amd/estimator.py::acquire_by_mutation for the re-expression of acquisition.rs:86-116, 177-202)
+    /// Mean and expected improvement for a batch (behaviour of gpr.rs:179-212) -- the entry the acquisition should use, one call
+    /// per generation (hbetune_rs_amd/estimator.py::acquire_by_mutation re-expresses acquisition.rs:86-116, 177-202 over it):
+    /// the incumbent goes into normalised units, EI is taken there per candidate on (mean, std), the mean comes back as a location.
     fn predict_mean_ei_a(&self, x: Array2<A>, fmin: A) -> (Array1<A>, Array1<A>) {
-        let (y, y_var) = self.predict_normalized(x.view(), true);
-        let y_var = y_var.expect("variance was requested");
-
-        let fmin = *self.y_norm.project_into_normalized(array![fmin]).first().unwrap();
-
-        let mut ei: Array1<A> = Array1::zeros(x.nrows());
-        ndarray::Zip::from(&mut ei).and(&y).and(&y_var).apply(|ei, &y, &var| {
-            *ei = A::from_f(expected_improvement(y.into(), var.sqrt().into(), fmin.into()))
-        });
-
-        let y = self.y_norm.project_location_from_normalized(y);
-        (y, ei)
+        let (mean_n, var_n) = self.predict_normalized(x.view(), true);
+        let var_n = var_n.expect("variance was requested");
+        let fmin_n: f64 = self.y_norm.project_into_normalized(array![fmin])[0].into();
+        let ei: Array1<A> = mean_n
+            .iter()
+            .zip(var_n.iter())
+            .map(|(&m, &v)| A::from_f(expected_improvement(m.into(), v.sqrt().into(), fmin_n)))
+            .collect();
+        (self.y_norm.project_location_from_normalized(mean_n), ei)
     }
 }
 
