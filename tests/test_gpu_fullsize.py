@@ -1,6 +1,7 @@
 """GPU, BASELINE.json's full sizes: size-independent properties of one evaluation / model (the oracle would take minutes
 at these sizes).  K comes from the CPU oracle's kernel (independent of the device assembly kernel)."""
 import math
+import os
 
 import numpy as np
 import pytest
