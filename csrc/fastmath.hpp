@@ -25,13 +25,13 @@ __device__ __forceinline__ double sqrt_nonneg(double x) {
   double sq = x * y;
   const double res = __builtin_fma(-sq, sq, x);
   sq = __builtin_fma(res * 0.5, y, sq);
-  return x > 0.0 ? sq : 0.0;
+  return x == 0.0 ? 0.0 : sq;  // rsq(NaN or x < 0) is NaN and stays NaN (a NaN feature must end in NOT_PD, lml.rs:47-50)
 }
 __device__ __forceinline__ float sqrt_nonneg(float x) { return sqrtf(x); }
 
 __device__ __forceinline__ double exp_nonpos(double x) {
 #pragma clang fp contract(off)
-  x = fmax(x, -750.0);
+  x = x < -750.0 ? -750.0 : x;  // not fmax: a NaN argument stays NaN
   const double t = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(-t, 6.93147180369123816490e-01, x);
   r = __builtin_fma(-t, 1.90821492927058770002e-10, r);

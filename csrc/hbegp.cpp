@@ -115,7 +115,12 @@ struct DevPool {
     }
     // a fresh block is cleared once, here: every later owner may rely on "finite numbers everywhere" (recycled blocks
     // hold finite results of their previous life)
-    e = hipMemset(p, 0, bytes);
+    // hipMemset on device memory returns before the fill has run (it is queued on the null stream), and the engine's streams are
+    // non-blocking ones that do not wait for the null stream: without the synchronisation below a first writer on such a stream
+    // (the model's copy of L^-1 in make_model) can be overtaken by the fill -- seen once in round 4 as a predictive variance that
+    // was off by O(1) on a fresh process, where every block is a fresh one.
+    e = hipMemsetAsync(p, 0, bytes, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
       (void)hipFree(p);
       throw HipError{e, "hipMemset (pool)", __LINE__};
@@ -569,6 +574,7 @@ struct Problem : ProblemBase {
               HIPCHECK(hipMemset(s.dag_trace, 0, sizeof(unsigned long long) * 5 * plan.tasks.size()));
             }
           }
+          HIPCHECK(hipStreamSynchronize(nullptr));  // the fills above are queued on the null stream; the slot streams do not wait for it
         }
       }
     }

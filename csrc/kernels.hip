@@ -15,6 +15,7 @@
 //  4*(l>>4)+r for f32).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -493,31 +494,180 @@ template void launch_gemm<float>(const GemmLaunch&, int, hipStream_t);
 // =================================================================================================================
 // Leaf: 128x128 diagonal block.  L = chol(A) (lower), X = L^-1.
 // =================================================================================================================
-#ifndef LEAF_DIAG_COPY
-#define LEAF_DIAG_COPY 1
-#endif
 template <typename T>
 struct LeafGeom {
-  static constexpr int S = 130;          // LDS row stride of the block image
-  static constexpr int YS = 18;          // row stride of a 16x16 sub-block image
-  static constexpr int YB = 16 * YS;     // elements per 16x16 image
-  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 8 * YB + 4 * YB + 128) * sizeof(T);  // 162,816 B for f64
+  static constexpr int S = 130;          // LDS row stride of the block image (and of the image of the 16x16 inverses)
+  static constexpr int YS = 18;          // row stride of a 16x16 scratch image
+  static constexpr int YB = 16 * YS;     // elements per 16x16 scratch image
+  static constexpr size_t LDS_BYTES = (size_t)(128 * S + 16 * S + 4 * YB + 128) * sizeof(T);  // 160,000 B for f64
 };
 
-// Structure (8 panels of 16 columns, one barrier-separated phase sequence per panel p):
-//   (A) wave 0 owns rows 16p .. 16p+63 (lane = row) and eliminates the panel in registers with lane broadcasts
-//       (v_readlane): this factors the 16x16 diagonal block AND solves the triangular system for the next three block
-//       rows in the same instruction stream.  No inverse of the diagonal block is needed on the critical path.
-//       Meanwhile waves 1-3: trailing update of panel p-1 (block columns >= p+1), Y_{p-1} = L_{p-1,p-1}^-1 by forward
-//       substitution (lane = column), block row p-2 of X = L^-1 on MFMA.
-//   (B) p < 4 only: wave 1 solves the rows beyond wave 0's window by substitution against L_pp (LDS broadcast reads)
-//       while waves 0,2,3 update the window rows of block column p+1;   (C) the remaining blocks of column p+1.
-// Tail: Y_7, block rows 6 and 7 of X.  fp64 MFMA for every 16x16x16 product.
+// ---- static item tables of the diagonal block's MFMA waves (see leaf_body) ---------------------------------------------------
+// Every 16x16x16 product the block needs is known in advance.  Per phase p the products of panels k = p-1 and k2 = p-2 are
+// listed class by class; an entry is four words {a, b, c, x}: byte offsets (LDS, from the block image) of the A operand, the B
+// operand and the result block, and one more number.  A wave reads an entry with ONE broadcast LDS read and adds its lane
+// pattern -- no scalar decoding, no class switch inside a loop: one wave issues one instruction per ~4.5 cycles whatever its kind,
+// so an item must stay below ~50 instructions to keep up with its four MFMAs (256 cycles of the SIMD's matrix pipe).
+//   F(j):      X[k,j] = -Y_k S[k,j], j < k         {j, S^T block (j,k), same, byte offset of column block j in a row of X}
+//   U(i,j):    A[i,j] -= L[i,k] L[j,k]^T           {L block (i,k), L block (j,k), block (i,j), 0},   p+1 <= j <= i <= 7
+//   G(i,j):    S[i,j] += L[i,k2] X[k2,j]           {L block (i,k2), X^T block (j,k2) or Yt_k2, S^T block (j,i), 0},  i >= p+1, j <= k2
+//   GU1(j):    S[p,j] += L[p,k2] X[k2,j], j <= k2  (as G)
+//   GU2(j):    S[p,j] += L[p,k] X[k,j],  j <= k    (as G; for j < k it waits for F(j)'s flag)
+constexpr int LEAF_S = 130;
+constexpr int LEAF_YT0 = 128 * LEAF_S;       // element offset of the image of the transposed 16x16 inverses: Y_q[r][c] at YT0 + c S + 16 q + r
+constexpr int LEAF_MAXITEMS = 26;
+struct LeafItemTab {
+  unsigned e[8][LEAF_MAXITEMS][4];
+};
+constexpr int LEAF_TAB_WORDS = 8 * LEAF_MAXITEMS * 4;
+constexpr unsigned leaf_blk_bytes(int i, int j) { return (unsigned)(((i * 16) * LEAF_S + j * 16) * 8); }
+constexpr unsigned leaf_yt_bytes(int q) { return (unsigned)((LEAF_YT0 + 16 * q) * 8); }
+// list sizes and offsets inside a phase's row (closed forms: leaf_body uses them instead of loading counts)
+constexpr int leaf_nf(int p) { return p - 1; }
+constexpr int leaf_nu(int p) { return (7 - p) * (8 - p) / 2; }
+constexpr int leaf_ng(int p) { return p >= 2 ? (7 - p) * (p - 1) : 0; }
+constexpr int leaf_ngu1(int p) { return p - 1; }
+constexpr int leaf_ngu2(int p) { return p; }
+constexpr LeafItemTab leaf_build_items(int xcol_bytes) {
+  LeafItemTab t{};
+  for (int p = 1; p < 8; ++p) {
+    const int k = p - 1, k2 = p - 2;
+    int n = 0;
+    for (int j = 0; j < k; ++j, ++n) {
+      t.e[p][n][0] = (unsigned)j; t.e[p][n][1] = leaf_blk_bytes(j, k); t.e[p][n][2] = leaf_blk_bytes(j, k); t.e[p][n][3] = (unsigned)(j * xcol_bytes);
+    }
+    for (int i = p + 1; i < 8; ++i)
+      for (int j = p + 1; j <= i; ++j, ++n) {
+        t.e[p][n][0] = leaf_blk_bytes(i, k); t.e[p][n][1] = leaf_blk_bytes(j, k); t.e[p][n][2] = leaf_blk_bytes(i, j);
+      }
+    if (k2 >= 0)
+      for (int i = p + 1; i < 8; ++i)
+        for (int j = 0; j <= k2; ++j, ++n) {
+          t.e[p][n][0] = leaf_blk_bytes(i, k2); t.e[p][n][1] = j == k2 ? leaf_yt_bytes(k2) : leaf_blk_bytes(j, k2); t.e[p][n][2] = leaf_blk_bytes(j, i);
+        }
+    for (int j = 0; j <= k2; ++j, ++n) {
+      t.e[p][n][0] = leaf_blk_bytes(p, k2); t.e[p][n][1] = j == k2 ? leaf_yt_bytes(k2) : leaf_blk_bytes(j, k2); t.e[p][n][2] = leaf_blk_bytes(j, p);
+    }
+    for (int j = 0; j <= k; ++j, ++n) {
+      t.e[p][n][0] = leaf_blk_bytes(p, k); t.e[p][n][1] = j == k ? leaf_yt_bytes(k) : leaf_blk_bytes(j, k); t.e[p][n][2] = leaf_blk_bytes(j, p);
+    }
+    t.e[p][LEAF_MAXITEMS - 1][3] = (unsigned)n;  // for the consistency check below only
+  }
+  return t;
+}
+constexpr bool leaf_items_consistent() {
+  const LeafItemTab t = leaf_build_items(128);
+  for (int p = 1; p < 8; ++p) {
+    const int n = leaf_nf(p) + leaf_nu(p) + leaf_ng(p) + leaf_ngu1(p) + leaf_ngu2(p);
+    if ((int)t.e[p][LEAF_MAXITEMS - 1][3] != n || n > LEAF_MAXITEMS - 1) return false;
+  }
+  return true;
+}
+static_assert(leaf_items_consistent(), "item table sizes");
+// Round-robin dealing of a phase's items to its MFMA waves continues across the lists: rotation of list L in phase p =
+// (items of the lists before L) mod (number of MFMA waves in phase p).  Packed 4 bits per list (F, U, G, GU) -- no division
+// at run time (an integer modulo costs ~30 instructions, i.e. more than half an item).
+constexpr int leaf_nworkers(int p) { return p < 4 ? 5 : 6; }
+constexpr unsigned leaf_rotations(int p) {
+  const int nw = leaf_nworkers(p);
+  const int g1 = leaf_nf(p), g2 = g1 + leaf_nu(p), g3 = g2 + leaf_ng(p);
+  return (unsigned)(0 | ((g1 % nw) << 4) | ((g2 % nw) << 8) | ((g3 % nw) << 12));
+}
+// copied into the LDS by every block (a scalar load from HBM per item would cost more than the item); one table per element type
+// of X in HBM (the F items carry the byte offset of a column block)
+__device__ const LeafItemTab g_leaf_items_f64 = leaf_build_items(16 * 8);
+__device__ const LeafItemTab g_leaf_items_f32 = leaf_build_items(16 * 4);
+
+// ---- lane broadcasts inside a 16-lane row, fused into the fp64 FMA (round 4) ------------------------------------------------
+// gfx950 carries DPP for the double-precision ALU with one control: row_newbcast:n = "lane n of my 16-lane row".  With the 16
+// pivot rows of a panel replicated in every 16-lane row of the wave, the multiplier l_jk every lane needs at pivot k is lane j of
+// its own row: the trailing update a_ij -= l_ik l_jk is ONE v_fmac_f64_dpp (4.7 cycles issue, tools/leaf_ubench) where rounds 1-3
+// spent two v_readlane_b32 + s_nop + v_fma_f64 (20 cycles) -- the elimination's instruction stream shrinks 2.5x.
+// The compiler knows nothing about what is inside an asm statement, in particular not that a DPP operand read needs two wait
+// states behind the VALU write of that register (CDNA3 ISA 4.5): every value that is read through DPP is therefore produced by
+// mul_then_gap() / consumed by row_bcast_safe(), which carry the wait states inside their own asm text.
+template <int J>
+__device__ __forceinline__ void fmac_nbc(double& d, double s0, double s1) {  // d -= (lane J of my row: s0) * s1
+  asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s0), "v"(s1), "n"(J));
+}
+template <int K>
+__device__ __forceinline__ double row_bcast_safe(double v) {  // lane K of my row's v; v may have been written by the previous instruction
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+  return r;
+}
+__device__ __forceinline__ double mul_then_gap(double a, double b) {  // a * b, safe to read through DPP right behind it
+  double r;
+  asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// One 16-column panel in registers.  a[]: the panel's 16 pivot rows, lane l holds row l & 15 (four replicas per wave);
+// b[]: 64 more rows of the panel, one per lane (rows below the pivot block, or rows of the identity).  At pivot K every lane
+// forms 1/sqrt(pivot) itself (the pivot is lane K of its row), scales its two columns K and applies the rank-1 update to the
+// columns behind.  A row of b ends as b L_pp^-T: a row below the pivot block becomes its row of L, row r of the identity becomes
+// column r of Y = L_pp^-1 (exact zeros above the diagonal) -- the inverse of the 16x16 factor costs no instruction of its own.
+// Entries above the diagonal of the pivot block only ever feed themselves: no per-lane predicates.
+// 1/sqrt(piv): hardware estimate (5e-8) + one third-order step r (1 + e/2 + 3e^2/8), e = 1 - piv r^2: 1.4e-16, the same as two
+// Newton steps (tools/rsq_probe.hip) in 5 dependent operations instead of 8.  A pivot that is not positive (or NaN) gives NaN for
+// its column and everything behind it: the caller tests the diagonal of L once, at the end.
+template <int K, int J>
+struct LeafCol {
+  static __device__ __forceinline__ void run(double (&a)[16], double (&b)[16], double lka, double lkb) {
+    fmac_nbc<J>(a[J], lka, lka);
+    fmac_nbc<J>(b[J], lka, lkb);
+    LeafCol<K, J + 1>::run(a, b, lka, lkb);
+  }
+};
+template <int K>
+struct LeafCol<K, 16> {
+  static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, double) {}
+};
+template <int K>
+struct LeafPivot {
+  static __device__ __forceinline__ void run(double (&a)[16], double (&b)[16]) {
+    const double piv = row_bcast_safe<K>(a[K]);
+    double rinv = __builtin_amdgcn_rsq(piv);
+    {
+      const double gg = piv * rinv;
+      const double ee = __builtin_fma(-gg, rinv, 1.0);
+      const double pp = __builtin_fma(ee, 0.375, 0.5);
+      rinv = __builtin_fma(rinv, ee * pp, rinv);
+    }
+    const double lka = mul_then_gap(a[K], rinv);  // l_{row,K} (pivot row: sqrt(piv))
+    const double lkb = b[K] * rinv;
+    a[K] = lka;
+    b[K] = lkb;
+    LeafCol<K, K + 1>::run(a, b, lka, lkb);
+    LeafPivot<K + 1>::run(a, b);
+  }
+};
+template <>
+struct LeafPivot<16> {
+  static __device__ __forceinline__ void run(double (&)[16], double (&)[16]) {}
+};
+
+// Structure (8 panels of 16 columns, two barrier-separated phases per panel p):
+//   (A) wave 0 eliminates the panel in registers (LeafPivot): pivot rows 16p..16p+15 replicated four times, plus the next (up to)
+//       64 rows.  While rows remain beyond that window (p < 4) one helper wave (wave 6) runs the SAME elimination -- redundantly,
+//       bitwise the same -- with the remaining rows, so they are ready together with the window without any communication.  The
+//       first 16 spare lanes of the helper (p < 4) or of wave 0 (p >= 4) carry the rows of the identity: Y_p = L_pp^-1.
+//       Meanwhile the other waves pull 16x16x16 MFMA items of panel p-1 from a pool (an LDS counter; an item's arithmetic does not
+//       depend on who runs it): the rest of the trailing update, and the inverse X = L^-1 in right-looking form --
+//         F(j):   X[k,j] = -Y_k S[k,j]            (block row k = p-1 of X is final)
+//         G(i,j): S[i,j] += L[i,k] X[k,j], i > k  (every later block row collects its sum as soon as a term exists)
+//       so that behind the last panel only X[7,j] = -Y_7 S[7,j] is left (rounds 1-3 formed whole block rows of X at the end:
+//       4,900 of the block's 53,000 cycles).  S[i,j] and later X[i,j] live TRANSPOSED in the strict upper blocks of the image,
+//       which is exactly the layout of an MFMA B operand: nothing is staged through a scratch image.
+//   (B) block column p+1 is updated for every remaining block row (one 16x16 block per wave).
+// fp64 MFMA for every 16x16x16 product, two accumulator chains per product (a dependent v_mfma_f64_16x16x4 issues every 66
+// cycles, tools/leaf_ubench).  Block indices are wave-uniform (scalar registers); a lane's part of every address is one of four
+// constants.
 // T = arithmetic type of the block (always double: the block is latency-bound, so f32 problems are factored in f64 too),
 // TIO = element type in HBM.
-__device__ long long g_leaf_stamps[64];
+__device__ long long g_leaf_stamps[256];
 #define LEAF_STAMP(i) do { if ((dbg & 8) && t == 0) g_leaf_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
-void read_leaf_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_leaf_stamps), sizeof(long long) * 64); }
+void read_leaf_stamps(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_leaf_stamps), sizeof(long long) * 256); }
 
 // Results another workgroup of the SAME launch will read (the task-queue kernel, dag_kernel.inc.hpp) are stored
 // write-through (sc1) so that they need no release fence; between launches plain stores do.
@@ -531,241 +681,322 @@ template <typename T, typename TIO, bool SC1>
 __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
                                           TIO* __restrict__ ldiag, int* info, int dbg, char* smem_raw,
                                           TIO* __restrict__ W3 = nullptr) {
+  static_assert(sizeof(T) == 8, "the diagonal block is factored in fp64");
   using C = Cfg<T>;
   using L = LeafGeom<T>;
   using acc_t = typename C::acc_t;
   using vec_t = typename Cfg<TIO>::vec_t;
   constexpr int S = L::S, YS = L::YS, YB = L::YB, VEC = Cfg<TIO>::VEC;
 
-  T* As = reinterpret_cast<T*>(smem_raw);  // [128][S]: lower = A -> L ; strict upper blocks = X^T
-  T* Ys = As + 128 * S;                    // [8][16][YS]: inverses of the diagonal 16x16 factors
-  T* Sc = Ys + 8 * YB;                     // [4][16][YS]: per-wave scratch
-  T* Rd = Sc + 4 * YB;                     // [128]: 1 / L_kk
+  T* As = reinterpret_cast<T*>(smem_raw);  // [128][S]: lower = A -> L ; strict upper blocks = S^T -> X^T
+  T* Yt = As + 128 * S;                    // [16][S]: TRANSPOSED inverses of the diagonal 16x16 factors, Y_q[r][c] at Yt[c * S + 16 q + r]
+  static_assert(S == LEAF_S, "the item tables are built for this row stride");
+  T* Sc = Yt + 16 * S;                     // [16][YS]: copy of the next panel's pivot block for the helper wave
+  T* Id = Sc + YB;                         // [17][YS]: the identity (rows 0-15) and a row of zeros (row 16)
+  int* pool = reinterpret_cast<int*>(Id + 17 * YS + 2);  // [8]: flags of the F items (+ 8 spare)
+  unsigned* tab = reinterpret_cast<unsigned*>(pool + 16);  // the item tables (g_leaf_items_*), 16-byte aligned
+  static_assert(((128 * S + 16 * S + YB + 17 * YS + 2) * sizeof(T) + 64) % 16 == 0, "item table alignment");
+  static_assert((YB + 17 * YS + 2) * sizeof(T) + 64 + LEAF_TAB_WORDS * 4 <= (4 * YB + 128) * sizeof(T), "the scratch region holds the item tables");
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // wave-uniform on purpose: block indices stay in scalar registers
   const int m16 = lane & 15, q4 = lane >> 4;
   const size_t g0 = (size_t)blk * NB * ld + (size_t)blk * NB;
   TIO* Ablk = W1 + g0;
   TIO* Xblk = W2 + g0;
 
-  // load the block: all 16-byte chunks of a batch are issued before the first LDS store, so the loads overlap
+  // Load the lower 16x16 blocks of the block; the strict upper blocks start as zeros (they will hold the sums S^T of the
+  // inverse).  Wave w takes block row w (rows 16w .. 16w+15, four threads per row): the trip count is wave-uniform, and all
+  // loads of a thread are issued before its first LDS store.
   {
-    constexpr int CPRW = 128 / VEC;             // chunks per row
-    constexpr int NCHUNK = 128 * CPRW / 512;     // chunks per thread
-    constexpr int BATCH = NCHUNK < 16 ? NCHUNK : 16;
+    const int r = t >> 2, sub = t & 3;           // row, position among the row's four threads
+    constexpr int CPR = 16 / VEC;                // 16-byte chunks per 16 columns
+    const int nch = (wave + 1) * CPR / 4;        // chunks of this thread: columns [0, 16 (wave + 1)) of its row, interleaved by 4
+    const TIO* src = Ablk + (size_t)r * ld + sub * VEC;
+    T* dst = As + r * S + sub * VEC;
+    constexpr int MAXCH = 8 * CPR / 4;
+    vec_t buf[MAXCH];
 #pragma unroll
-    for (int b0 = 0; b0 < NCHUNK; b0 += BATCH) {
-      vec_t buf[BATCH];
+    for (int q = 0; q < MAXCH; ++q)
+      if (q < nch) buf[q] = *reinterpret_cast<const vec_t*>(src + q * 4 * VEC);
 #pragma unroll
-      for (int q = 0; q < BATCH; ++q) {
-        const int c = t + 512 * (b0 + q);
-        const int r = c / CPRW, cc = (c % CPRW) * VEC;
-        buf[q] = *reinterpret_cast<const vec_t*>(Ablk + (size_t)r * ld + cc);
-      }
+    for (int q = 0; q < MAXCH; ++q) {
 #pragma unroll
-      for (int q = 0; q < BATCH; ++q) {
-        const int c = t + 512 * (b0 + q);
-        const int r = c / CPRW, cc = (c % CPRW) * VEC;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) As[r * S + cc + e] = (T)buf[q][e];
-      }
+      for (int e = 0; e < VEC; ++e) dst[q * 4 * VEC + e] = q < nch ? (T)buf[q][e] : T(0);
     }
   }
-#if LEAF_DIAG_COPY
-  // the first diagonal 16x16 block once more, into Sc: the helper waves take the pivot rows from there (see the elimination)
-  if (t < 256) Sc[(t >> 4) * YS + (t & 15)] = (T)Ablk[(size_t)(t >> 4) * ld + (t & 15)];
-#endif
+  // the first diagonal 16x16 block once more, into Sc: the helper wave takes the pivot rows from there (see the elimination)
+  if (t < 256) {
+    Sc[(t >> 4) * YS + (t & 15)] = (T)Ablk[(size_t)(t >> 4) * ld + (t & 15)];
+  } else {
+    for (int e = t - 256; e < 17 * 16; e += 256) Id[(e >> 4) * YS + (e & 15)] = ((e >> 4) == (e & 15)) ? T(1) : T(0);
+    if (t < 256 + 16) pool[t - 256] = 0;  // the F flags
+  }
+  {
+    const unsigned* gt = reinterpret_cast<const unsigned*>(sizeof(TIO) == 8 ? &g_leaf_items_f64 : &g_leaf_items_f32);
+    for (int e = t; e < LEAF_TAB_WORDS; e += 512) tab[e] = gt[e];
+  }
   __syncthreads();
 
   LEAF_STAMP(0);
-  // diag_copy: the block is the next panel's diagonal block and helper waves will eliminate it a second time: keep a copy in Sc
-  auto update_block = [&](int i, int j, int pp, bool diag_copy = false) {  // A[i,j] -= L[i,pp] L[j,pp]^T
-    acc_t acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const T af = As[(i * 16 + m16) * S + pp * 16 + k4 * 4 + q4];
-      const T bf = As[(j * 16 + m16) * S + pp * 16 + k4 * 4 + q4];
-      acc = C::mfma(af, bf, acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      T* pc = &As[(i * 16 + C::crow(lane, r)) * S + j * 16 + m16];
-      const T v = *pc - acc[r];
-      *pc = v;
-#if LEAF_DIAG_COPY
-      if (diag_copy) Sc[C::crow(lane, r) * YS + m16] = v;
-#endif
-    }
+  // ---- 16x16x16 MFMA items on 16x16 blocks of the LDS image.  A lane adds one of two patterns to an entry's byte offsets:
+  //   P0 = row m16 of the block, element q4 (+ 4 per step): operands stored [outer][k], and a TRANSPOSED result
+  //   P1 = row q4 (+ 4 per step), column m16: a result in normal orientation (U), and Y_q read from the Yt image as an A operand (F)
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const int P0 = (m16 * S + q4) * (int)sizeof(T), P1 = (q4 * S + m16) * (int)sizeof(T);
+  constexpr int STEP0 = 4 * (int)sizeof(T), STEP1 = 4 * S * (int)sizeof(T);
+  constexpr int CLS_U = 0, CLS_G = 1, CLS_F = 2;
+  char* lds0 = reinterpret_cast<char*>(As);
+  int* fflag = pool;  // [8]: fflag[j] = p once F(j) of phase p has written X[p-1, j]
+  auto ldsT = [&](int byte_off) -> T& { return *reinterpret_cast<T*>(lds0 + byte_off); };
+  // An item in two halves, so that two items can be in flight in one wave: issue = operand loads + the four MFMAs on two
+  // accumulator chains (a dependent v_mfma_f64_16x16x4 issues every 66 cycles), finish = combine, store.
+  struct Prod {
+    T cf[4];
+    acc_t a0, a1;
   };
-
-  // X = L^-1 block by block: X[i,i] = Y_ii ; X[i,j] = -Y_ii * sum_{k=j}^{i-1} L[i,k] X[k,j]  (i > j).
-  // X[k,j] (k > j) is kept transposed in the upper part of As; block row i only needs rows < i, L[i,:] and Y_ii.
-  auto xinv_block = [&](int i, int j) {
-    acc_t acc = {0, 0, 0, 0};
-    for (int k = j; k < i; ++k) {
+  // ya: byte offset of Y_k in the Yt image (F items: their A operand)
+  auto item_issue = [&](auto cls, const u4 d, int ya, Prod& pr) {
+    constexpr int CLS = decltype(cls)::value;
+    T af[4], bf[4];
+    if constexpr (CLS == CLS_F) {
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
-        const T af = As[(i * 16 + m16) * S + k * 16 + k4 * 4 + q4];
-        T bf;
-        if (k == j) bf = Ys[j * YB + (k4 * 4 + q4) * YS + m16];
-        else bf = As[(j * 16 + m16) * S + k * 16 + k4 * 4 + q4];
-        acc = C::mfma(af, bf, acc);
+      for (int k4 = 0; k4 < 4; ++k4) af[k4] = ldsT(ya + P1 + k4 * STEP1);
+    } else {
+      const int pa = (int)d[0] + P0;
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) af[k4] = ldsT(pa + k4 * STEP0);
+    }
+    const int pb = (int)d[1] + P0;
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) bf[k4] = ldsT(pb + k4 * STEP0);
+    if constexpr (CLS == CLS_U) {
+      const int pc = (int)d[2] + P1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr.cf[r] = ldsT(pc + r * STEP1);
+    } else if constexpr (CLS == CLS_G) {
+      const int pc = (int)d[2] + P0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr.cf[r] = ldsT(pc + r * STEP0);
+    }
+    pr.a0 = acc_t{0, 0, 0, 0};
+    pr.a1 = acc_t{0, 0, 0, 0};
+    pr.a0 = C::mfma(af[0], bf[0], pr.a0);
+    pr.a1 = C::mfma(af[2], bf[2], pr.a1);
+    pr.a0 = C::mfma(af[1], bf[1], pr.a0);
+    pr.a1 = C::mfma(af[3], bf[3], pr.a1);
+  };
+  // xrow: F items, this lane's first element of block row k of X in HBM (row q4 of the block row, column m16); dcopy: the
+  // result is the next panel's pivot block, the helper wave will eliminate it a second time: keep a copy in Sc
+  auto item_finish = [&](auto cls, const u4 d, const Prod& pr, TIO* xrow, bool dcopy) {
+    constexpr int CLS = decltype(cls)::value;
+    if constexpr (CLS == CLS_U) {
+      const int pc = (int)d[2] + P1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T v = pr.cf[r] - (pr.a0[r] + pr.a1[r]);
+        ldsT(pc + r * STEP1) = v;
+        if (dcopy) Sc[(q4 + 4 * r) * YS + m16] = v;
+      }
+    } else if constexpr (CLS == CLS_G) {
+      const int pc = (int)d[2] + P0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ldsT(pc + r * STEP0) = pr.cf[r] + (pr.a0[r] + pr.a1[r]);
+    } else {
+      const int pc = (int)d[2] + P0;
+      TIO* xp = reinterpret_cast<TIO*>(reinterpret_cast<char*>(xrow) + d[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T v = -pr.a0[r] - pr.a1[r];
+        ldsT(pc + r * STEP0) = v;  // in place of S^T: every lane's operand reads are complete, the products have consumed them
+        gstore<SC1>(xp + (size_t)(4 * r) * ld, (TIO)v);
       }
     }
-    // stage the sum through LDS to re-read it as a B operand: in the place its result will occupy (the transposed image
-    // of X[i,j] in the upper part of As), so every wave can run this without a scratch image of its own
-    T* stage = &As[(j * 16) * S + i * 16];  // element (r, c) of the sum at stage[c * S + r]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) stage[m16 * S + C::crow(lane, r)] = acc[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    acc_t res = {0, 0, 0, 0};
-#pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const T af = Ys[i * YB + m16 * YS + k4 * 4 + q4];
-      const T bf = stage[m16 * S + k4 * 4 + q4];
-      res = C::mfma(af, bf, res);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = C::crow(lane, r);
-      const T v = -res[r];
-      As[(j * 16 + m16) * S + i * 16 + row] = v;             // transposed copy for later products
-      gstore<SC1>(&Xblk[(size_t)(i * 16 + row) * ld + j * 16 + m16], (TIO)v);  // X[i,j]
-    }
   };
-
-  // Y_q = L_qq^-1 by forward substitution, lane j (< 16) owns column j; L entries are LDS broadcast reads
-  auto yinv_block = [&](int q) {
-    const int j = m16;
-    T y[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      T sacc = (i == j) ? T(1) : T(0);
-#pragma unroll
-      for (int k = 0; k < i; ++k) sacc = __builtin_fma(-As[(q * 16 + i) * S + q * 16 + k], y[k], sacc);
-      y[i] = sacc * Rd[q * 16 + i];
+  using cU = std::integral_constant<int, CLS_U>;
+  using cG = std::integral_constant<int, CLS_G>;
+  using cF = std::integral_constant<int, CLS_F>;
+  auto xrow_of = [&](int k) { return Xblk + (size_t)(k * 16 + q4) * ld + m16; };
+  // Phase A(p) of the MFMA waves: the products of panels k = p-1 and k2 = p-2, class by class --
+  //   F(j,k), j < k                       block row k of X is final (sets fflag[j] = p)
+  //   U(i,j,k), p+1 <= j <= i <= 7        the rest of the trailing update of panel k
+  //   G(i,j,k2), i >= p+1, j <= k2        the sums of the later block rows collect the terms of block row k2 of X (final since
+  //                                       the previous phase; one phase late, so that they wait for nothing)
+  //   GU(j), j <= k                       S[p,j] += L[p,k2] X[k2,j] and += L[p,k] X[k,j]: block row p is finalised in the NEXT
+  //                                       phase, so its last term cannot be late -- it waits for F(j,k)'s flag instead
+  // Items are dealt round-robin to the MFMA waves, continuing across the lists (an LDS atomic per claim cost ~300 cycles with
+  // six waves asking at once -- more than an item): waves 1, 2, 3, 5, 7 while wave 6 is the helper (p < 4), then 1, 2, 3, 5,
+  // 6, 7.  F, U and G items are independent of one another: a wave keeps two of them in flight.  Every wave runs its F items
+  // before its GU items, so a wait for an F flag always ends.
+  auto pool_phase = [&](int p) {
+    const int k = p - 1;
+    const int nworkers = p < 4 ? 5 : 6;
+    const int widx = wave <= 3 ? wave - 1 : (wave == 5 ? 3 : (p < 4 ? 4 : wave - 2));
+    const u4* tabp = reinterpret_cast<const u4*>(tab) + p * LEAF_MAXITEMS;
+    const int ya = (int)leaf_yt_bytes(0) + k * 16 * (int)sizeof(T);
+    TIO* xrow = xrow_of(k);
+    // rotations of the four lists (leaf_rotations), selected without a table in memory
+    const unsigned rots = p == 1 ? leaf_rotations(1) : p == 2 ? leaf_rotations(2) : p == 3 ? leaf_rotations(3) : p == 4 ? leaf_rotations(4)
+                        : p == 5 ? leaf_rotations(5) : p == 6 ? leaf_rotations(6) : leaf_rotations(7);
+    auto first_of = [&](int list) {
+      const int f = widx - (int)((rots >> (4 * list)) & 15u);
+      return f < 0 ? f + nworkers : f;
+    };
+    auto run_list = [&](auto cls, int list, int o, int n) {
+      const int first = first_of(list);
+      for (int i = first; i < n; i += 2 * nworkers) {
+        const bool two = i + nworkers < n;
+        const u4 d0 = tabp[o + i];
+        const u4 d1 = tabp[o + (two ? i + nworkers : i)];
+        Prod p0, p1;
+        item_issue(cls, d0, ya, p0);
+        if (two) item_issue(cls, d1, ya, p1);
+        item_finish(cls, d0, p0, xrow, false);
+        if (two) item_finish(cls, d1, p1, xrow, false);
+        if constexpr (decltype(cls)::value == CLS_F) {  // publish the columns: the last term of S[p, j] waits for them
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) {
+            __hip_atomic_store(&fflag[d0[0]], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (two) __hip_atomic_store(&fflag[d1[0]], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    };
+    const bool inv = !(dbg & 2);  // timing switches of tools/leaf_bench: dbg 2 = no inverse, dbg 4 = no trailing update
+    if ((dbg & 8) && lane == 0) g_leaf_stamps[64 + (p * 8 + wave) * 2] = (long long)__builtin_readcyclecounter();
+    int o = 0;
+    if (inv) run_list(cF{}, 0, o, leaf_nf(p));
+    o += leaf_nf(p);
+    if (!(dbg & 4)) run_list(cU{}, 1, o, leaf_nu(p));
+    o += leaf_nu(p);
+    if (inv) run_list(cG{}, 2, o, leaf_ng(p));
+    o += leaf_ng(p);
+    if (inv) {
+      const int o1 = o, o2 = o + leaf_ngu1(p);
+      for (int j = first_of(3); j < p; j += nworkers) {
+        Prod pr;
+        if (j <= p - 2) {  // the term of k2
+          const u4 d = tabp[o1 + j];
+          item_issue(cG{}, d, ya, pr);
+          item_finish(cG{}, d, pr, xrow, false);
+        }
+        if (j < k) {
+          while (__hip_atomic_load(&fflag[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != p) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+        }
+        const u4 d = tabp[o2 + j];  // the term of k: same result block (LDS accesses of one wave stay in order)
+        item_issue(cG{}, d, ya, pr);
+        item_finish(cG{}, d, pr, xrow, false);
+      }
     }
-    if (lane < 16) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) Ys[q * YB + i * YS + j] = y[i];
-    }
+    if ((dbg & 8) && lane == 0) g_leaf_stamps[65 + (p * 8 + wave) * 2] = (long long)__builtin_readcyclecounter();
   };
+  auto blk_bytes = [&](int i, int j) { return (unsigned)(((i * 16) * S + j * 16) * (int)sizeof(T)); };
 
+  typedef T v2 __attribute__((ext_vector_type(2)));
   for (int p = 0; p < 8; ++p) {
-    // Elimination of panel p.  Wave 0 owns the 64-row window.  While p < 4 there are 64 - 16p rows beyond it: helper
-    // waves run the SAME elimination with lanes 0-15 on the diagonal rows again (redundantly, bitwise the same values) and
-    // lanes 16-63 on up to 48 of those far rows -- no communication, and the far rows are ready together with the window
-    // instead of in a separate substitution phase.  Helpers: wave 6 (far rows 0-47), and for p = 0 also wave 5 (48-63).
-    const int helper = (p < 4 && !(dbg & 4)) ? (wave == 6 ? 1 : ((wave == 5 && p == 0) ? 2 : 0)) : 0;
+    // Elimination of panel p.  Wave 0: the pivot rows and the (up to) 64 rows behind them.  While p < 4 there are 48 - 16p rows
+    // beyond that window: the helper (wave 6) runs the SAME elimination on the pivot rows -- bitwise the same values -- with
+    // those far rows in its b lanes, so they are ready together with the window.  The 16 lanes behind a wave's last row carry
+    // the identity (helper for p < 4, wave 0 from p = 4 on) and end as the columns of Y_p.
+    const bool helper = p < 4 && wave == 6;
     if (wave == 0 || helper) {
       if (!(dbg & 1)) {
-        const int nwin = min(64, 128 - 16 * p);
-        const int nfar = 64 - 16 * p;                      // rows beyond the window (helpers only)
-        const int far = (helper - 1) * 48 + (lane - 16);  // index of this lane's far row
-        const bool mine = helper ? (lane >= 16 && far < nfar) : (lane < nwin);
-        const int row = helper ? ((lane < 16) ? 16 * p + lane : (far < nfar ? 16 * p + 64 + far : 16 * p))
-                               : 16 * p + ((lane < nwin) ? lane : 0);
-        // dbg bit 4 (tests): the helper waves start ~3 us late -- longer than wave 0's whole elimination.  Results must not
+        const int nrows = helper ? 48 - 16 * p : min(64, 112 - 16 * p);  // rows of the block in this wave's b lanes
+        const int brow = 16 * p + 16 + (helper ? 64 : 0) + lane;        // the row of lane < nrows
+        const bool has_y = helper || p >= 4;
+        const int yr = lane - nrows;                                   // has_y: identity row of lanes nrows .. nrows + 15
+        // dbg bit 4 (tests): the helper wave starts ~3 us late -- longer than wave 0's whole elimination.  Results must not
         // change: nothing a helper reads is written by another wave in this phase (tests/test_gpu_dag.py).
         if ((dbg & 16) && helper) {
           __builtin_amdgcn_s_sleep(127);
           asm volatile("" ::: "memory");
         }
-        T a[16];
-#if LEAF_DIAG_COPY
-        // Wave 0 overwrites the pivot rows with L at the end of this phase, and no barrier orders a helper's reads of them
-        // before that: the helpers take them from the copy in Sc (written a phase earlier, behind a barrier) -- same values.
-        const T* src = (helper && lane < 16) ? Sc + lane * YS : As + row * S + p * 16;
+        T a[16], b[16];
+        {
+          // Wave 0 overwrites the pivot rows with L at the end of this phase, and no barrier orders the helper's reads of them
+          // before that: the helper takes them from the copy in Sc (written a phase earlier, behind a barrier) -- same values.
+          const T* srca = helper ? Sc + m16 * YS : As + (16 * p + m16) * S + p * 16;
+          // lanes without a row of the block: a row of the identity, or zeros
+          const T* srcb = lane < nrows ? As + brow * S + p * 16 : Id + ((has_y && yr < 16) ? yr : 16) * YS;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = src[j];
-#else
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = As[row * S + p * 16 + j];
-#endif
-        bool bad = false;
-        T rinv_own = T(0);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const T piv = readlane(a[k], k);
-          bad = bad || !(piv > T(0));
-          // 1/sqrt(piv): hardware estimate (5e-8) + one third-order step r (1 + e/2 + 3e^2/8), e = 1 - piv r^2: 1.4e-16,
-          // the same as two Newton steps (tools/rsq_probe.hip) in 5 dependent operations instead of 8
-          T rinv = __builtin_amdgcn_rsq(piv);
-          {
-            const T gg = piv * rinv;
-            const T ee = __builtin_fma(-gg, rinv, T(1));
-            const T pp = __builtin_fma(ee, T(0.375), T(0.5));
-            rinv = __builtin_fma(rinv, ee * pp, rinv);
+          for (int j = 0; j < 16; j += 2) {
+            const v2 va = *reinterpret_cast<const v2*>(srca + j);
+            a[j] = va[0];
+            a[j + 1] = va[1];
           }
-          const T lk = a[k] * rinv;  // l_{row,k} for rows at or below the pivot (pivot row: sqrt(piv))
-          a[k] = lk;
-          rinv_own = (lane == k) ? rinv : rinv_own;
-          // entries above the diagonal of the 16x16 block only ever feed themselves: no per-lane predicates needed
 #pragma unroll
-          for (int j = k + 1; j < 16; ++j) a[j] = __builtin_fma(-lk, readlane(lk, j), a[j]);
+          for (int j = 0; j < 16; j += 2) {
+            const v2 vb = *reinterpret_cast<const v2*>(srcb + j);
+            b[j] = vb[0];
+            b[j + 1] = vb[1];
+          }
         }
-        if (mine) {
+        LEAF_STAMP(40 + 3 * p);
+        LeafPivot<0>::run(a, b);
+        LEAF_STAMP(41 + 3 * p);
+        if (lane < nrows || (has_y && yr < 16)) {
+          // a row of the block -> its row of L; row yr of the identity -> column yr of Y_p = row yr of Yt[p]
+          T* dst = lane < nrows ? As + brow * S + p * 16 : Yt + yr * S + p * 16;
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (lane >= 16 || j <= lane) As[row * S + p * 16 + j] = a[j];
+          for (int j = 0; j < 16; j += 2) *reinterpret_cast<v2*>(dst + j) = v2{b[j], b[j + 1]};
         }
-        if (lane < 16 && !helper) {
-          T dv = T(0);
+        if (!helper && lane < 16) {
+          // the pivot block: L_pp (what lies above its diagonal is never read again)
+          T* dst = As + (16 * p + lane) * S + p * 16;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) dv = (j == lane) ? a[j] : dv;
-          gstore<SC1>(&ldiag[blk * NB + p * 16 + lane], (TIO)dv);  // read by the alpha tasks of the same launch
-          Rd[p * 16 + lane] = rinv_own;
+          for (int j = 0; j < 16; j += 2) *reinterpret_cast<v2*>(dst + j) = v2{a[j], a[j + 1]};
         }
-        if (bad && lane == 0 && !helper) atomicCAS(info, 0, 1 + blk * NB + p * 16);
+        LEAF_STAMP(42 + 3 * p);
       }
-    } else if (p > 0) {
-      // the other waves meanwhile: Y_{p-1} (wave 7), block row p-2 of the inverse, rest of the trailing update of panel
-      // p-1 (blocks (i,j), p+1 <= j <= i <= 7).  Six workers: while p < 4 wave 6 is a helper; from p = 4 on, when
-      // there is little of this work, wave 4 stays idle instead -- it shares a SIMD with wave 0, whose elimination is
-      // instruction-issue bound (measured: 10 % slower with wave 4 working).
-      if (wave == 7 && !(dbg & 2)) yinv_block(p - 1);
-      const int idle = (p < 4 && !(dbg & 4)) ? 6 : 4;
-      const int wslot = wave - 1 - (wave > idle ? 1 : 0);  // 0..5 over the six working waves
-      const int nx = ((dbg & 2) || p < 3) ? 0 : p - 2;
-      const int tcount = 7 - p;
-      const int nupd = (dbg & 4) ? 0 : tcount * (tcount + 1) / 2;
-      if (wave != idle) {
-        for (int j = wslot; j < nx; j += 6) xinv_block(p - 2, j);  // at most five blocks: one per wave
-        // updates start at the waves that got no inverse block
-        for (int u = (wslot + 6 - nx % 6) % 6; u < nupd; u += 6) {
-          const int li = tri_row(u), lj = u - li * (li + 1) / 2;
-          update_block(p + 1 + li, p + 1 + lj, p - 1);
-        }
-      }
+    } else if (p > 0 && wave != 4) {
+      // the other waves meanwhile (wave 4 stays idle: it shares a SIMD with wave 0, whose elimination is instruction-issue bound)
+      pool_phase(p);
     }
     __syncthreads();
     LEAF_STAMP(1 + 2 * p);
     if (p == 7) break;
     if (dbg & 4) continue;
 
-    // block column p+1 for every remaining block row (window rows from wave 0, far rows from the helpers)
-    for (int i = p + 1 + wave; i < 8; i += 8) update_block(i, p + 1, p, i == p + 1 && p + 1 < 4);
+    // block column p+1 for every remaining block row (window rows from wave 0, far rows from the helper)
+    if (p + 1 + wave < 8) {
+      const u4 d = {blk_bytes(p + 1 + wave, p), blk_bytes(p + 1, p), blk_bytes(p + 1 + wave, p + 1), 0u};
+      Prod pr;
+      item_issue(cU{}, d, 0, pr);
+      item_finish(cU{}, d, pr, nullptr, wave == 0 && p + 1 < 4);
+    }
     __syncthreads();
     LEAF_STAMP(2 + 2 * p);
   }
 
-  // ---------------- tail of the inverse: Y_7 and block row 6 of X, then block row 7 ----------------
+  // ---------------- tail of the inverse: block row 7 of X ----------------
   if (!(dbg & 2)) {
-    if (wave == 7) yinv_block(7);
-    else if (wave >= 1) xinv_block(6, wave - 1);   // six blocks, waves 1-6
-    __syncthreads();
-    if (wave >= 1) xinv_block(7, wave - 1);        // seven blocks, waves 1-7
+    if (wave >= 1) {  // X[7,j] = -Y_7 S[7,j]: seven blocks, waves 1-7
+      const int j = wave - 1;
+      const u4 d = {(unsigned)j, blk_bytes(j, 7), blk_bytes(j, 7), (unsigned)(j * 16 * (int)sizeof(TIO))};
+      Prod pr;
+      item_issue(cF{}, d, (int)leaf_yt_bytes(7), pr);
+      item_finish(cF{}, d, pr, xrow_of(7), false);
+    }
     __syncthreads();
   }
   LEAF_STAMP(20);
   // diagonal sub-blocks of X
   for (int c = t; c < 8 * 256; c += 512) {
     const int pblk = c >> 8, r = (c >> 4) & 15, j = c & 15;
-    gstore<SC1>(&Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j], (TIO)Ys[pblk * YB + r * YS + j]);
+    gstore<SC1>(&Xblk[(size_t)(pblk * 16 + r) * ld + pblk * 16 + j], (TIO)Yt[j * S + 16 * pblk + r]);
+  }
+  // diag(L) (read by the alpha tasks of the same launch) and the positive-definite test: a pivot that was not positive has left
+  // NaN on the diagonal from its column on
+  if (t < 64) {
+    const T dv0 = As[t * S + t], dv1 = As[(t + 64) * S + t + 64];
+    gstore<SC1>(&ldiag[blk * NB + t], (TIO)dv0);
+    gstore<SC1>(&ldiag[blk * NB + 64 + t], (TIO)dv1);
+    const unsigned long long bad0 = __ballot(!(dv0 > T(0))), bad1 = __ballot(!(dv1 > T(0)));
+    if ((bad0 | bad1) != 0ull && t == 0) {
+      const int first = bad0 != 0ull ? (int)__builtin_ctzll(bad0) : 64 + (int)__builtin_ctzll(bad1);
+      atomicCAS(info, 0, 1 + blk * NB + (first & ~15));  // reported per 16-column panel, as rounds 1-3 did
+    }
   }
   // optional: the factor itself (lower triangle of the block), for the f32 path's refinement of the panel solve
   if (W3) {

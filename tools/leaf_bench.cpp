@@ -39,7 +39,7 @@ int main() {
   launch_leaf<double>(W1, W2, np, 0, ld, info, 0, 8 | extra);
   printf("dbg=%d ", extra);
   hipDeviceSynchronize();
-  long long st[64];
+  long long st[256];
   read_leaf_stamps(st);
   printf("cycles: load->0");
   for (int p = 0; p < 8; ++p) {
@@ -47,6 +47,18 @@ int main() {
     if (p < 7) printf(" phase2 %lld", st[2 + 2 * p] - st[1 + 2 * p]);
   }
   printf(" | tail %lld | total %lld\n", st[20] - st[15], st[20] - st[0]);
+  printf("      MFMA waves in the pool [start after phase start + duration], waves 1 2 3 5 6 7:");
+  for (int p = 1; p < 8; ++p) {
+    printf(" p%d:", p);
+    for (int w : {1, 2, 3, 5, 6, 7}) {
+      const long long a = st[64 + (p * 8 + w) * 2], b = st[65 + (p * 8 + w) * 2];
+      if (a > 0 && b > 0) printf(" %lld+%lld", a - st[2 * p], b - a); else printf(" -");
+    }
+  }
+  printf("\n");
+  printf("      wave 0 per panel [phase start -> loads done | elimination | stores]:");
+  for (int p = 0; p < 8; ++p) printf(" p%d: %lld|%lld|%lld", p, st[40 + 3 * p] - (p == 0 ? st[0] : st[2 * p]), st[41 + 3 * p] - st[40 + 3 * p], st[42 + 3 * p] - st[41 + 3 * p]);
+  printf("\n");
   }
   return 0;
 }
