@@ -57,7 +57,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(w, theta, Xs, n_evals, reps=5):
+def cpu_baseline(w, theta, Xs, n_evals, reps=5, parity=None):
     """The reference's CPU path restated, timed on this box's host cores in the same run.  Main line (`value`):
     oracle/gpr_oracle.py -- the reference-faithful algorithm incl. the materialised dK tensor and LAPACK potrf/potrs/potri -- on
     ONE thread (the reference builds OpenBLAS with USE_THREAD=0, Makefile:3-4): median of `reps` full-size lml+gradient
@@ -83,6 +83,8 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
         t0 = time.perf_counter()
         O.predict(Xs, w["X"], res["alpha"], res["k_inv"], c, ell, 2.5)
         t_pred = time.perf_counter() - t0
+    if parity is not None:
+        parity(O, res)  # the checker's results are in hand: put the GPU's next to them (never inside a timed region)
     t_eval = sorted(t_evals)[len(t_evals) // 2]
     fit_predict_s = n_evals * t_eval + t_pred
     out = {
@@ -153,6 +155,57 @@ def cpu_baseline(w, theta, Xs, n_evals, reps=5):
         out["torch_cholesky_plus_inverse_s"] = {"1_thread": tt[1], f"{many}_threads": tt[many]}
     except Exception as e:
         out["torch_cholesky_plus_inverse_s"] = {"error": str(e)}
+    return out
+
+
+PARITY_BAR = 1e-8  # north_star: f64 results within 1e-8 of the reference's CPU path
+
+
+def parity_in_run(gpr, ctx, w, theta, Xs, timed_model, O, ref):
+    """The oracle (the CHECKER -- the reference's lml.rs:29-79 / predict.rs:7-52 restated, oracle/gpr_oracle.py) next to the GPU at
+    the headline size, in the run that produced the number: (a) one lml+gradient evaluation and a model built at the bench's theta
+    against the oracle's evaluation at that theta (already computed by the cpu_baseline leg); (b) the TIMED model (the last
+    fixed-work fit of the timed region) against one more oracle evaluation at the theta that fit captured.  Deviations are
+    relative to max(1, scale) as in tests/test_gpu_parity.py; the variance is relative to the amplitude."""
+    import numpy as np
+
+    X, y = w["X"], w["y"]
+    s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+    prob = gpr.Problem(X, y, nu=2.5, ctx=ctx)
+    lml, grad = prob.lml_with_gradient(theta)
+    alpha, kinv, _ = prob.results()
+    prob.close()
+    fk = gpr.FittedKernel.extend(X, y, theta, nu=2.5, ctx=ctx)
+    mean, var, _ = fk.predict(Xs)
+    fk.release()
+    rm, rv, _ = O.predict(Xs, X, ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    rel = lambda got, want: float(np.max(np.abs(np.asarray(got) - np.asarray(want))) / max(1.0, float(np.max(np.abs(want)))))
+    out = {
+        "bar": PARITY_BAR,
+        "lml_rel": abs(lml - ref["lml"]) / max(1.0, abs(ref["lml"])),
+        "grad_rel": rel(grad, ref["grad"]),
+        "alpha_rel": rel(alpha, ref["alpha"]),
+        "kinv_rel": rel(np.tril(kinv), np.tril(ref["k_inv"])),
+        "mean_abs": rel(mean, rm),
+        "var_abs": float(np.max(np.abs(var - rv)) / c),
+        "at": "the bench's theta (SURVEY 8d), n=%d d=%d, m=%d candidates" % (X.shape[0], X.shape[1], len(Xs)),
+    }
+    if timed_model is not None:
+        tm = timed_model["theta"]
+        s2t, ct, ellt = math.exp(tm[0]), math.exp(tm[1]), np.exp(tm[2:])
+        log("parity: one more oracle evaluation at the timed fit's captured theta")
+        rt = O.lml_with_gradient(X, y, s2t, ct, ellt, 2.5)
+        rmt, rvt, _ = O.predict(Xs, X, rt["alpha"], rt["k_inv"], ct, ellt, 2.5)
+        out["timed_model"] = {
+            "lml_rel": abs(timed_model["lml"] - rt["lml"]) / max(1.0, abs(rt["lml"])),
+            "mean_abs": rel(timed_model["mean"], rmt),
+            "var_abs": float(np.max(np.abs(timed_model["var"] - rvt)) / ct),
+            "at": "the theta captured by the last timed fit; its predictions at the m candidates are the timed ones",
+        }
+    worst = max([v for k, v in out.items() if k.endswith(("_rel", "_abs"))] +
+                [v for k, v in out.get("timed_model", {}).items() if k.endswith(("_rel", "_abs"))])
+    out["worst"] = worst
+    out["ok"] = bool(worst <= PARITY_BAR)
     return out
 
 
@@ -392,6 +445,7 @@ def main():
                                   fixed_work=True)
         fit_stats["n_evals"], fit_stats["n_not_pd"] = fk.n_evals, fk.n_not_pd
         mean, var, _ = fk.predict(Xs)
+        fit_stats["model"] = {"theta": fk.theta.copy(), "lml": fk.lml, "mean": mean, "var": var}  # what the parity leg checks afterwards
         fk.release()
         return mean, var
 
@@ -508,11 +562,26 @@ def main():
             out["small_n_side_line"] = dict(small, note="config M data cut to n rows, d=8, f64, 3 runs x 150 evaluations, best of 3 fits")
         except Exception as e:
             out["small_n_side_line"] = {"error": str(e)}
+        parity_failed = False
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(w, theta, Xs, fit_stats.get("n_evals") or (1 + N_RESTARTS) * EVALS_PER_RUN)
+            par = {}
+
+            def parity(O, ref):
+                log("parity: the GPU's evaluation, model and the timed model next to the oracle")
+                par.update(parity_in_run(gpr, ctx, w, theta, Xs, fit_stats.get("model"), O, ref))
+
+            cb = cpu_baseline(w, theta, Xs, fit_stats.get("n_evals") or (1 + N_RESTARTS) * EVALS_PER_RUN, parity=parity)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_port"] = value / cb["value"]
+            out["parity_in_run"] = par
+            parity_failed = not par.get("ok", False)
         print(json.dumps(out), flush=True)
+        if parity_failed:
+            log(f"PARITY FAILED: worst deviation {out['parity_in_run'].get('worst')} above {PARITY_BAR}")
+            if dist is not None:
+                dist.destroy_process_group()
+            ctx.close()
+            sys.exit(3)
     if dist is not None:
         D.barrier(dist)
         dist.destroy_process_group()

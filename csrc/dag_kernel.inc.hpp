@@ -471,17 +471,17 @@ __device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
 template <typename T>
 #if DAG_LEAF_NOINLINE == 2
 // variant 2: the function names the workgroup's dynamic LDS itself, so the block keeps local-address-space (ds_) accesses
-__device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char*) {
+__device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char*, int dbg) {
   extern __shared__ __align__(16) char leaf_smem[];
-  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, leaf_smem);
+  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, dbg, leaf_smem);
 }
 #elif DAG_LEAF_NOINLINE
-__device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
-  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, smem_raw);
+__device__ __attribute__((noinline)) void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw, int dbg) {
+  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, dbg, smem_raw);
 }
 #else
-__device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw) {
-  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, 0, smem_raw);
+__device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, char* smem_raw, int dbg) {
+  leaf_body<double, T, true>(W1, W2, ld, blk, ldiag, info, dbg, smem_raw);
 }
 #endif
 
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
     };
     if (status == 0) {
       if (kind == DAG_LEAF) {
-        dag_leaf_task<T>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, smem_raw);
+        dag_leaf_task<T>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, smem_raw, g.leaf_dbg & 16);  // only the test bit: the timing bits stay with tools/leaf_bench
       } else if ((flags & DAGF_CKINV) && g.Kinv == nullptr) {
         // factorisation-only launch: the K^-1 tiles are not wanted
       } else if (kind == DAG_GEMM_128x64) {

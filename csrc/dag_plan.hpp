@@ -704,6 +704,17 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
   };
   for (int i = 0; i < nt; ++i) {
     const DagTask& t = plan.tasks[i];
+    // A tile that STARTS its accumulation from the stored values (DAGF_CINIT) is only defined the way build_lauum emits it:
+    // beta = 1, alpha = +1 and a non-empty contraction range (an empty one would store zeros over the first part's sums on the
+    // 128x64 path, dag_gemm_tile); f32 problems never split (an f32 partial sum would be rounded on its way through memory):
+    // build_lauum splits at the f64 stage depth only.
+    if ((t.kind == DAG_GEMM_128x64 || t.kind == DAG_GEMM_64x64) && (t.flags & DAGF_CINIT)) {
+      if (!(t.flags & DAGF_ACC) || (t.flags & DAGF_NEG) || t.kend <= t.kbeg) {
+        snprintf(buf, sizeof buf, "task %d: DAGF_CINIT needs DAGF_ACC, no DAGF_NEG and a non-empty contraction range (flags %x, k [%d, %d))", i,
+                 t.flags, t.kbeg, t.kend);
+        return buf;
+      }
+    }
     std::fill(cur.begin(), cur.end(), 0);
     for (int w = 0; w < t.nwait; ++w) {
       const int c = t.wcnt[w];

@@ -143,6 +143,7 @@ struct DagLaunch {
   EvalOut* out;
   unsigned long long* trace;  // optional (diagnostics): per task [pulled, inputs ready, computed, published] on the 100 MHz clock, then the CU id
   unsigned long long wait_ticks;  // bound of one dependency wait in ticks of the 100 MHz clock (host: from the plan's simulated makespan)
+  int leaf_dbg;                   // debug bits of the diagonal-block tasks (tests: 16 = the helper wave starts late, HBEGP_LEAF_DBG)
 };
 template <typename T>
 void launch_dag(const DagLaunch& g, int nwg, hipStream_t s);

@@ -786,6 +786,7 @@ struct Problem : ProblemBase {
       g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
       g.trace = s.dag_trace;
       g.wait_ticks = dag_wait_ticks_;
+      g.leaf_dbg = leaf_dbg_;
       if (tm) tm->begin(PhaseTimer::DAG, 0, g.Kinv ? dag_gflop : dag_gflop - dag_gflop_lauum);
       launch_dag<T>(g, var.nwg, s.stream);
       if (tm) tm->end();
@@ -1054,6 +1055,15 @@ struct Problem : ProblemBase {
     // non-finite trace, must not reach the optimiser as a number
     bool finite = std::isfinite(*lml);
     if (grad) for (int j = 0; j < p; ++j) finite = finite && std::isfinite(grad[j]);
+    if (!finite) {
+      // Which of the two?  launch_reset_out poisons the outputs with ONE bit pattern (a quiet NaN with payload 0x5eed) that no
+      // arithmetic produces: an output that still carries it was never written -- an engine bug, reported as such, not a
+      // property of the data.  Any other non-finite value is a genuine one (NaN features, overflow).
+      auto poisoned = [](double v) { unsigned long long b; memcpy(&b, &v, 8); return b == 0x7ff8000000005eedull; };
+      bool never_written = poisoned(s.hOut->lml);
+      if (grad) for (int j = 0; j < p; ++j) never_written = never_written || poisoned(s.hOut->grad[j]);
+      if (never_written) throw HipError{hipErrorLaunchFailure, "evaluation: an output of the lml/gradient kernels was never written", __LINE__};
+    }
     if (!finite) {  // handled like a failed factorisation (lml.rs:47-50 -> fit.rs:105-112): objective +inf, zero gradient, never captured
       *lml = -std::numeric_limits<double>::infinity();
       if (grad) for (int j = 0; j < p; ++j) grad[j] = 0.0;
@@ -1437,7 +1447,9 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   for (int di = 0; di < ndev; ++di) n_slots = std::max(n_slots, std::min(runs_on[di], max_conc));
   static const int timing = env_int("HBEGP_TIMING", 0);
   const auto tf0 = std::chrono::steady_clock::now();
-  Problem<T> prob(ctx, X, y, n, d, nu, n_slots);
+  // like_fit: the evaluation path (launches / task queue) is a function of n alone, also for a fit with one slot per device
+  // (n_restarts = 0, or no more runs than devices): `extend` at the fitted theta then repeats the fit's own evaluation bit for bit
+  Problem<T> prob(ctx, X, y, n, d, nu, n_slots, false, true);
   const auto tf1 = std::chrono::steady_clock::now();
 
   std::vector<double> lnlo(p), lnhi(p);

@@ -567,7 +567,10 @@ static_assert(leaf_items_consistent(), "item table sizes");
 // Round-robin dealing of a phase's items to its MFMA waves continues across the lists: rotation of list L in phase p =
 // (items of the lists before L) mod (number of MFMA waves in phase p).  Packed 4 bits per list (F, U, G, GU) -- no division
 // at run time (an integer modulo costs ~30 instructions, i.e. more than half an item).
-constexpr int leaf_nworkers(int p) { return p < 4 ? 5 : 6; }
+#ifndef LEAF_WAVE4_WORKS
+#define LEAF_WAVE4_WORKS 1  /* wave 4 shares a SIMD with wave 0 and slows its elimination by a fifth (2370 -> 2870-3140 cycles), but the MFMA items are what a phase waits for: 25.8 -> 24.7 us per block */
+#endif
+constexpr int leaf_nworkers(int p) { return (p < 4 ? 5 : 6) + LEAF_WAVE4_WORKS; }
 constexpr unsigned leaf_rotations(int p) {
   const int nw = leaf_nworkers(p);
   const int g1 = leaf_nf(p), g2 = g1 + leaf_nu(p), g3 = g2 + leaf_ng(p);
@@ -830,8 +833,9 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
   // before its GU items, so a wait for an F flag always ends.
   auto pool_phase = [&](int p) {
     const int k = p - 1;
-    const int nworkers = p < 4 ? 5 : 6;
-    const int widx = wave <= 3 ? wave - 1 : (wave == 5 ? 3 : (p < 4 ? 4 : wave - 2));
+    const int nworkers = leaf_nworkers(p);
+    // waves 1, 2, 3, 5, 7 (+ 6 from p = 4 on), wave 4 last
+    const int widx = wave <= 3 ? wave - 1 : (wave == 4 ? nworkers - 1 : (wave == 5 ? 3 : (p < 4 ? 4 : wave - 2)));
     const u4* tabp = reinterpret_cast<const u4*>(tab) + p * LEAF_MAXITEMS;
     const int ya = (int)leaf_yt_bytes(0) + k * 16 * (int)sizeof(T);
     TIO* xrow = xrow_of(k);
@@ -949,8 +953,8 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
         }
         LEAF_STAMP(42 + 3 * p);
       }
-    } else if (p > 0 && wave != 4) {
-      // the other waves meanwhile (wave 4 stays idle: it shares a SIMD with wave 0, whose elimination is instruction-issue bound)
+    } else if (p > 0 && (LEAF_WAVE4_WORKS || wave != 4)) {
+      // the other waves meanwhile
       pool_phase(p);
     }
     __syncthreads();
@@ -1735,7 +1739,7 @@ void launch_set_info(int* info, int value, hipStream_t s) { hipLaunchKernelGGL(s
 
 __global__ void reset_out_kernel(EvalOut* out) {
   const int t = threadIdx.x;
-  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  const double nan = __longlong_as_double(0x7ff8000000005eedLL);  // the poison pattern run_eval looks for (a payload no arithmetic produces)
   if (t == 0) {
     out->lml = nan; out->yalpha = nan; out->logdet = nan;
     out->info = 0; out->n_warn = 0; out->done = 0;

@@ -174,18 +174,20 @@ def test_concurrent_soak_against_launch_path(rl, monkeypatch):
             assert _close(r[0], got[i][0], 1e-11) and _close(r[1], got[i][1], 1e-11), i
 
 
-@pytest.mark.parametrize("n", [128, 640, 1100])
-def test_diagonal_block_helper_waves_may_start_late(n, monkeypatch):
+@pytest.mark.parametrize("n,dag", [(128, "0"), (640, "0"), (1100, "0"), (2048, "1")])
+def test_diagonal_block_helper_waves_may_start_late(n, dag, monkeypatch):
     # Root cause of round 2's run-to-run deviations (profiles/r03_leaf_race.txt): the helper waves of the
     # diagonal-block kernel re-read the pivot rows that wave 0 overwrites with L at the end of the same phase, with no barrier
     # in between -- correct only while a helper is not more than part of wave 0's elimination late.  The helpers now read a
     # copy nobody writes during the phase (LEAF_DIAG_COPY).  HBEGP_LEAF_DBG=16 holds every helper back ~3 us, longer than
     # wave 0's whole elimination: lml, gradient, alpha, K^-1 and diag(L) must not change in a single bit.  (A library built
-    # with -DLEAF_DIAG_COPY=0 fails this test at every n.)
+    # without that copy fails this test at every n.)  dag = "1" at n = 2048: the task queue's diagonal block -- the called,
+    # write-through instantiation every evaluation from n = 2048 on runs (default right-looking plan); the debug bit reaches it
+    # through DagLaunch::leaf_dbg.
     w = synth.make_workload("M", n=n)
     X, y, theta = w["X"], w["y"], w["theta"]
-    ref = _eval_all(X, y, theta, monkeypatch, "0")
-    got = _eval_all(X, y, theta, monkeypatch, "0", HBEGP_LEAF_DBG=16)
+    ref = _eval_all(X, y, theta, monkeypatch, dag)
+    got = _eval_all(X, y, theta, monkeypatch, dag, HBEGP_LEAF_DBG=16)
     for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(ref, got):
         assert r0 is not None and r1 is not None
         assert r0[0] == r1[0] and np.array_equal(r0[1], r1[1])

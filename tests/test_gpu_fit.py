@@ -42,6 +42,8 @@ def test_fit_trace_replays_on_oracle_and_capture_rule():
     bounds = list(zip(w["lo"], w["hi"]))
     best = -math.inf
     checked = 0
+    eps = np.finfo(np.float64).eps
+    worst = {"lml": 0.0, "grad": 0.0, "cond": 0.0}
     for i in range(len(tr["lml"])):
         th = tr["theta"][i]
         assert np.all(th >= np.log(w["lo"]) - 1e-12) and np.all(th <= np.log(w["hi"]) + 1e-12)
@@ -50,11 +52,19 @@ def test_fit_trace_replays_on_oracle_and_capture_rule():
             if res is None:
                 assert tr["lml"][i] == -math.inf
             else:
-                scale = max(1.0, abs(f))
-                assert abs(-f - tr["lml"][i]) <= 1e-7 * scale, (i, f, tr["lml"][i])
-                np.testing.assert_allclose(tr["grad"][i], -g, rtol=0, atol=1e-7 * max(1.0, np.abs(g).max()))
+                # the north star's 1e-8, relative to max(1, scale) -- unless cond(K) at this theta puts the ORACLE's own digits
+                # beyond it: both sides solve with K, so neither is good to better than ~cond(K) eps; the allowance then is
+                # 100 cond(K) eps (the optimiser does visit such corners of the box: tiny noise, long length scales)
+                cond = float(np.linalg.cond(res["kernel_matrix"]))
+                bar = max(1e-8, 100.0 * cond * eps)
+                dl = abs(-f - tr["lml"][i]) / max(1.0, abs(f))
+                dg = float(np.max(np.abs(tr["grad"][i] + g))) / max(1.0, np.abs(g).max())
+                assert dl <= bar and dg <= bar, (i, dl, dg, cond, bar)
+                worst = {"lml": max(worst["lml"], dl), "grad": max(worst["grad"], dg), "cond": max(worst["cond"], cond)}
             checked += 1
         best = max(best, tr["lml"][i])
+    print(f"trace replay: {checked} evaluations on the oracle, worst deviation / scale: lml {worst['lml']:.2e}, gradient {worst['grad']:.2e}; "
+          f"largest cond(K) along the trajectory {worst['cond']:.2e}")
     assert checked > 10
     # capture = arg-max over every evaluation of every run (fit.rs:116-125)
     assert fk.lml == best
@@ -62,8 +72,9 @@ def test_fit_trace_replays_on_oracle_and_capture_rule():
     i_best = int(np.argmax(tr["lml"]))
     f, g, res = O.objective(tr["theta"][i_best], X, y, 2.5, bounds)
     alpha, kinv = fk.arrays()
-    np.testing.assert_allclose(alpha, res["alpha"], rtol=0, atol=1e-7 * max(1.0, np.abs(res["alpha"]).max()))
-    np.testing.assert_allclose(kinv, res["k_inv"], rtol=0, atol=1e-7 * np.abs(res["k_inv"]).max())
+    bar = max(1e-8, 100.0 * float(np.linalg.cond(res["kernel_matrix"])) * eps)
+    np.testing.assert_allclose(alpha, res["alpha"], rtol=0, atol=bar * max(1.0, np.abs(res["alpha"]).max()))
+    np.testing.assert_allclose(kinv, res["k_inv"], rtol=0, atol=bar * max(1.0, np.abs(res["k_inv"]).max()))
     # fitting must improve on the start point
     assert fk.lml > tr["lml"][0]
 
@@ -258,14 +269,18 @@ def test_incremental_extend_falls_back_when_the_prefix_differs():
         prior.extend_with(X[:, :4], y)  # wrong feature count
 
 
+@pytest.mark.parametrize("n_restarts", [2, 0])
 @pytest.mark.parametrize("n,dtype", [(700, np.float64), (1100, np.float64), (1300, np.float32)])
-def test_extend_repeats_the_fits_own_evaluation_bit_for_bit(n, dtype):
+def test_extend_repeats_the_fits_own_evaluation_bit_for_bit(n, dtype, n_restarts):
     # One order of operations for one theta: `extend` at the fitted theta runs the evaluation the way the
     # fit ran it (launches below 8 blocks, the task queue from there on, whose single-slot K^-1 split continues the undivided
     # tiles' accumulation), so lml, alpha and K^-1 are the captured evaluation's, bit for bit.
+    # n_restarts = 0: a fit with ONE slot per device (it used to pick its path with the single-evaluation threshold of
+    # 16 blocks while extend used the fit's 8 -- different orders of operations for n = 1024..1920); the path is now a function of
+    # n alone.
     w = synth.make_workload("M", n=n)
     X, y = w["X"].astype(dtype), w["y"].astype(dtype)
-    starts = synth.restart_points("M", w["lo"], w["hi"], 2)
+    starts = synth.restart_points("M", w["lo"], w["hi"], n_restarts) if n_restarts else None
     fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, maxeval=25, trace=True)
     best = int(np.argmax(fk.trace["lml"]))  # the captured evaluation (first maximum, fit.rs:116-125); its theta as the optimiser passed it
     assert fk.trace["lml"][best] == fk.lml

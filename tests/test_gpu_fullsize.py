@@ -76,6 +76,43 @@ def test_full_size_properties(cfg):
         assert np.linalg.norm(back - v) <= (5e-2 if f32 else 1e-8) * np.linalg.norm(v) * 10
 
 
+@pytest.mark.parametrize("cfg", ["M", "C3", "C4"])
+def test_full_size_against_the_oracle(cfg):
+    """The f64 BASELINE configurations at their FULL size next to the oracle (lml.rs:29-79, predict.rs:7-52 restated with the
+    reference's own LAPACK calls), through the default path -- the right-looking task queue, the code that produces the
+    headline number: lml, gradient, alpha, the lower triangle of K^-1, and mean / variance at 64 candidates, all at 1e-8
+    (relative to max(1, scale); the variance relative to the amplitude).  M: n=4096 d=8; C3: n=4096 d=16; C4: n=8192 d=2
+    (logarithmic projection).  Host time of the oracle: ~6 / ~12 / ~40 s."""
+    w = synth.make_workload(cfg)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    assert X.dtype == np.float64
+    s2, c, ell = _theta_parts(theta)
+    n, d = X.shape
+    ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+    prob = gpr.Problem(X, y)
+    lml, grad = prob.lml_with_gradient(theta)
+    alpha, kinv, ldiag = prob.results()
+    prob.close()
+    tol = 1e-8
+    cond_lb = float((ldiag.max() / ldiag.min()) ** 2)  # a lower bound on cond(K) from the factor's diagonal
+    dev = {
+        "lml": abs(lml - ref["lml"]) / max(1.0, abs(ref["lml"])),
+        "grad": float(np.max(np.abs(grad - ref["grad"])) / max(1.0, np.abs(ref["grad"]).max())),
+        "alpha": float(np.max(np.abs(alpha - ref["alpha"])) / max(1.0, np.abs(ref["alpha"]).max())),
+        "k_inv": float(np.max(np.abs(np.tril(kinv) - np.tril(ref["k_inv"]))) / max(1.0, np.abs(ref["k_inv"]).max())),
+    }
+    del kinv
+    fk = gpr.FittedKernel.extend(X, y, theta)
+    Xs = synth.candidates(cfg, 64, d)
+    mean, var, _ = fk.predict(Xs)
+    fk.release()
+    rm, rv, _ = O.predict(Xs, X, ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    dev["mean"] = float(np.max(np.abs(mean - rm)) / max(1.0, np.abs(rm).max()))
+    dev["var"] = float(np.max(np.abs(var - rv)) / c)
+    print(f"{cfg} n={n} d={d}: deviation from the oracle / scale: {dev}; cond(K) >= {cond_lb:.2e}")
+    assert all(v <= tol for v in dev.values()), (dev, cond_lb)
+
+
 def test_c3_eight_restart_fit_short():
     # C3: 8 optimiser runs (1 + 7 restarts) on one GPU, shortened to 6 evaluations per run; the capture must be the
     # arg-max over all 48 evaluations and the model must predict with that theta
@@ -134,5 +171,5 @@ def test_c5_full_size_f32_against_both_oracles(noise_over_amplitude):
     # (HBEGP_DAG=0 / HBEGP_DAG_RL=0: panel solves through the explicit inverse of the whole left half) K^-1 sits at 1.2e-4 at
     # cond(K) = 7e4 -- inside the rule above (LAPACK f32: 1.7e-4), outside the plain bar -- so the plain bar is asserted for
     # the default configuration only (tools/gpu_matrix.sh runs the suite under the forced configurations).
-    if os.environ.get("HBEGP_DAG") is None and os.environ.get("HBEGP_DAG_RL") is None:
+    if os.environ.get("HBEGP_DAG") != "0" and os.environ.get("HBEGP_DAG_RL") != "0":
         assert all(v[0] <= 1e-4 for v in report.values()), report

@@ -328,3 +328,28 @@ def test_random_shapes_against_oracle(n, d, nu, dtype, seed):
     fk.release()
     np.testing.assert_allclose(mean, rm, rtol=0, atol=tol * max(1.0, np.abs(rm).max()))
     np.testing.assert_allclose(var, rv, rtol=0, atol=tol * c * (10 if dtype == np.float32 else 1))
+
+
+@pytest.mark.parametrize("n,dtype", [(300, np.float64), (300, np.float32), (2300, np.float64)])
+def test_nan_features_stay_nan(n, dtype):
+    # the fast fp64 sqrt / exp of kmat / gradtrace / kstar used to turn a NaN argument into distance 0 (K entry = c), so a
+    # NaN in X or in the candidates silently gave a finite model.  The reference propagates it: the Cholesky fails and the
+    # objective is +inf (lml.rs:47-50); a NaN candidate predicts NaN (predict.rs:18-37).  Both element types, both evaluation paths.
+    w = synth.make_workload("C2", n=n)
+    X, y, theta = w["X"].astype(dtype), w["y"].astype(dtype), w["theta"]
+    bad = X.copy()
+    bad[17, 1] = np.nan
+    prob = gpr.Problem(bad, y)
+    assert prob.lml_with_gradient(theta) is None  # NOT_PD: objective +inf, zero gradient (fit.rs:105-112)
+    prob.close()
+    with pytest.raises(gpr.HbegpError):
+        gpr.FittedKernel.extend(bad, y, theta)  # "Kernel matrix must be invertible." (fit.rs:55)
+    fk = gpr.FittedKernel.extend(X, y, theta)
+    for m in (5, 64):  # the path for a handful of candidates and the batched path
+        Xs = synth.candidates("C2", m, X.shape[1]).astype(dtype)
+        Xs[3, 0] = np.nan
+        mean, var, _ = fk.predict(Xs)
+        assert np.isnan(mean[3]) and np.isnan(var[3])
+        ok = np.arange(m) != 3
+        assert np.all(np.isfinite(mean[ok])) and np.all(np.isfinite(var[ok]))
+    fk.release()
