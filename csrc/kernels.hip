@@ -513,13 +513,17 @@ struct LeafGeom {
 //   G(i,j):    S[i,j] += L[i,k2] X[k2,j]           {L block (i,k2), X^T block (j,k2) or Yt_k2, S^T block (j,i), 0},  i >= p+1, j <= k2
 //   GU1(j):    S[p,j] += L[p,k2] X[k2,j], j <= k2  (as G)
 //   GU2(j):    S[p,j] += L[p,k] X[k,j],  j <= k    (as G; for j < k it waits for F(j)'s flag)
+#ifndef LEAF_WAVE4_WORKS
+#define LEAF_WAVE4_WORKS 1  /* wave 4 shares a SIMD with wave 0 and slows its elimination by a fifth (2370 -> 2870-3140 cycles), but the MFMA items are what a phase waits for: 25.8 -> 24.7 us per block */
+#endif
 constexpr int LEAF_S = 130;
 constexpr int LEAF_YT0 = 128 * LEAF_S;       // element offset of the image of the transposed 16x16 inverses: Y_q[r][c] at YT0 + c S + 16 q + r
 constexpr int LEAF_MAXITEMS = 26;
 struct LeafItemTab {
   unsigned e[8][LEAF_MAXITEMS][4];
+  unsigned par[8][8][4];  // [phase][wave]: {first item of this wave in the F | U << 8 | G << 16 | GU << 24 list, number of MFMA waves, 0, 0}
 };
-constexpr int LEAF_TAB_WORDS = 8 * LEAF_MAXITEMS * 4;
+constexpr int LEAF_TAB_WORDS = 8 * LEAF_MAXITEMS * 4 + 8 * 8 * 4;
 constexpr unsigned leaf_blk_bytes(int i, int j) { return (unsigned)(((i * 16) * LEAF_S + j * 16) * 8); }
 constexpr unsigned leaf_yt_bytes(int q) { return (unsigned)((LEAF_YT0 + 16 * q) * 8); }
 // list sizes and offsets inside a phase's row (closed forms: leaf_body uses them instead of loading counts)
@@ -552,6 +556,23 @@ constexpr LeafItemTab leaf_build_items(int xcol_bytes) {
       t.e[p][n][0] = leaf_blk_bytes(p, k); t.e[p][n][1] = j == k ? leaf_yt_bytes(k) : leaf_blk_bytes(j, k); t.e[p][n][2] = leaf_blk_bytes(j, p);
     }
     t.e[p][LEAF_MAXITEMS - 1][3] = (unsigned)n;  // for the consistency check below only
+    // Round-robin dealing of the phase's items to its MFMA waves, continuing across the lists: waves 1, 2, 3, 5, 7 while wave 6
+    // is the helper (p < 4), then 1, 2, 3, 5, 6, 7; wave 4 (it shares a SIMD with the eliminating wave 0) comes last.  The
+    // first item of every wave in every list is tabulated: no division at run time (an integer modulo costs ~30
+    // instructions -- more than half an item).
+    const int nw = (p < 4 ? 5 : 6) + LEAF_WAVE4_WORKS;
+    const int starts[4] = {0, leaf_nf(p), leaf_nf(p) + leaf_nu(p), leaf_nf(p) + leaf_nu(p) + leaf_ng(p)};  // GU: its own numbering (j)
+    for (int w = 0; w < 8; ++w) {
+      const int widx = w <= 3 ? w - 1 : (w == 4 ? nw - 1 : (w == 5 ? 3 : (p < 4 ? 4 : w - 2)));
+      unsigned packed = 0;
+      for (int l = 0; l < 4; ++l) {
+        int f = widx - starts[l] % nw;
+        if (f < 0) f += nw;
+        packed |= (unsigned)(widx < 0 ? 255 : f) << (8 * l);
+      }
+      t.par[p][w][0] = packed;
+      t.par[p][w][1] = (unsigned)nw;
+    }
   }
   return t;
 }
@@ -564,18 +585,6 @@ constexpr bool leaf_items_consistent() {
   return true;
 }
 static_assert(leaf_items_consistent(), "item table sizes");
-// Round-robin dealing of a phase's items to its MFMA waves continues across the lists: rotation of list L in phase p =
-// (items of the lists before L) mod (number of MFMA waves in phase p).  Packed 4 bits per list (F, U, G, GU) -- no division
-// at run time (an integer modulo costs ~30 instructions, i.e. more than half an item).
-#ifndef LEAF_WAVE4_WORKS
-#define LEAF_WAVE4_WORKS 1  /* wave 4 shares a SIMD with wave 0 and slows its elimination by a fifth (2370 -> 2870-3140 cycles), but the MFMA items are what a phase waits for: 25.8 -> 24.7 us per block */
-#endif
-constexpr int leaf_nworkers(int p) { return (p < 4 ? 5 : 6) + LEAF_WAVE4_WORKS; }
-constexpr unsigned leaf_rotations(int p) {
-  const int nw = leaf_nworkers(p);
-  const int g1 = leaf_nf(p), g2 = g1 + leaf_nu(p), g3 = g2 + leaf_ng(p);
-  return (unsigned)(0 | ((g1 % nw) << 4) | ((g2 % nw) << 8) | ((g3 % nw) << 12));
-}
 // copied into the LDS by every block (a scalar load from HBM per item would cost more than the item); one table per element type
 // of X in HBM (the F items carry the byte offset of a column block)
 __device__ const LeafItemTab g_leaf_items_f64 = leaf_build_items(16 * 8);
@@ -828,24 +837,18 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
   //   GU(j), j <= k                       S[p,j] += L[p,k2] X[k2,j] and += L[p,k] X[k,j]: block row p is finalised in the NEXT
   //                                       phase, so its last term cannot be late -- it waits for F(j,k)'s flag instead
   // Items are dealt round-robin to the MFMA waves, continuing across the lists (an LDS atomic per claim cost ~300 cycles with
-  // six waves asking at once -- more than an item): waves 1, 2, 3, 5, 7 while wave 6 is the helper (p < 4), then 1, 2, 3, 5,
-  // 6, 7.  F, U and G items are independent of one another: a wave keeps two of them in flight.  Every wave runs its F items
+  // six waves asking at once -- more than an item; the dealing is tabulated, LeafItemTab::par).  F, U and G items are independent of one another: a wave keeps two of them in flight.  Every wave runs its F items
   // before its GU items, so a wait for an F flag always ends.
   auto pool_phase = [&](int p) {
     const int k = p - 1;
-    const int nworkers = leaf_nworkers(p);
-    // waves 1, 2, 3, 5, 7 (+ 6 from p = 4 on), wave 4 last
-    const int widx = wave <= 3 ? wave - 1 : (wave == 4 ? nworkers - 1 : (wave == 5 ? 3 : (p < 4 ? 4 : wave - 2)));
+    // this wave's first item in each list and the number of MFMA waves: one broadcast read of the phase's parameter record
+    const u4 par = *reinterpret_cast<const u4*>(tab + 8 * LEAF_MAXITEMS * 4 + (p * 8 + wave) * 4);
+    const unsigned firsts = (unsigned)__builtin_amdgcn_readfirstlane((int)par[0]);
+    const int nworkers = __builtin_amdgcn_readfirstlane((int)par[1]);
     const u4* tabp = reinterpret_cast<const u4*>(tab) + p * LEAF_MAXITEMS;
     const int ya = (int)leaf_yt_bytes(0) + k * 16 * (int)sizeof(T);
     TIO* xrow = xrow_of(k);
-    // rotations of the four lists (leaf_rotations), selected without a table in memory
-    const unsigned rots = p == 1 ? leaf_rotations(1) : p == 2 ? leaf_rotations(2) : p == 3 ? leaf_rotations(3) : p == 4 ? leaf_rotations(4)
-                        : p == 5 ? leaf_rotations(5) : p == 6 ? leaf_rotations(6) : leaf_rotations(7);
-    auto first_of = [&](int list) {
-      const int f = widx - (int)((rots >> (4 * list)) & 15u);
-      return f < 0 ? f + nworkers : f;
-    };
+    auto first_of = [&](int list) { return (int)((firsts >> (8 * list)) & 255u); };
     auto run_list = [&](auto cls, int list, int o, int n) {
       const int first = first_of(list);
       for (int i = first; i < n; i += 2 * nworkers) {
