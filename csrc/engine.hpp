@@ -191,6 +191,54 @@ template <typename T>
 void launch_predict_small(const T* Xs, int m, const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* alpha, const T* Linv,
                           T* Ks, double* pmean, double* w, int want_var, T* mean, T* var, int* n_warn, hipStream_t s);
 
+// One evaluation of a problem of at most 128 rows (np = NB, d <= SMALL_EVAL_MAXD) in ONE launch, everything in the LDS
+// (kernels.hip: small_eval_kernel).  mode bit 0: alpha + lml, bit 1: K^-1, bit 2: gradient.
+constexpr int SMALL_EVAL_MAXD = 32;
+struct SmallEval {
+  const void* X;
+  const void* y;
+  int n, d;
+  const EvalParams* P;
+  void* W2;
+  void* ldiag;
+  void* Kinv;
+  void* alpha;
+  EvalOut* out;    // device memory: the diagonal block's positive-definite flag (atomics)
+  EvalOut* hout;   // where the results go: the slot's pinned host block (written by the kernel itself: no copy node) or `out`
+  int mode;
+};
+template <typename T>
+void launch_small_eval(const SmallEval& g, int nu2, hipStream_t s);
+
+// One optimiser run of a fit of at most 128 rows in ONE launch (kernels.hip: small_fit_kernel): the evaluation above in a loop
+// with the bounded L-BFGS step and the fit's objective wrapper (clamping, failed evaluations, capture of the best) on the device.
+struct LbfgsState;
+struct SmallFitResult {
+  double best_lml;
+  double best_theta[MAXP];   // as the optimiser passed it (log space, unclamped noise)
+  int best_idx;              // ping-pong buffer (K^-1, alpha) that holds the captured evaluation; -1: every evaluation failed
+  int best_eval;             // its index within the run
+  int n_evals, n_not_pd;
+};
+struct SmallFit {
+  SmallEval ev;              // X, y, n, d, P (device workspace, written by the kernel), W2, ldiag, out = hout (device workspace)
+  void* Kinv[2];
+  void* alpha[2];
+  LbfgsState* st;            // device workspace
+  const double* x0;          // start point (log space), p = d + 2 entries
+  const double* lo;          // linear-space box
+  const double* hi;
+  int maxeval, memory, fixed_work;
+  double pgtol, ftol;
+  SmallFitResult* res;       // device
+  double* trace_theta;       // [trace_cap][p] (device; may be null with trace_cap = 0)
+  double* trace_lml;         // [trace_cap]
+  double* trace_grad;        // [trace_cap][p]
+  int trace_cap;
+};
+template <typename T>
+void launch_small_fit(const SmallFit& f, int nu2, hipStream_t s);
+
 void launch_set_info(int* info, int value, hipStream_t s);
 // start of an evaluation: info = n_warn = done = 0, lml and gradient poisoned with NaN (a launch that was rejected or
 // skipped can then never pass for a result)

@@ -33,6 +33,7 @@
 #include "dag_plan.hpp"
 #include "engine.hpp"
 #include "lbfgsb.hpp"
+#include "lbfgs_step.hpp"
 
 
 using namespace hbegp;
@@ -147,6 +148,76 @@ struct DevPool {
   }
 };
 static DevPool g_pool;
+
+// Pinned host blocks and streams are recycled as well: a fit of a small problem lasts ~10 ms, and creating + destroying its
+// slots' streams, pinned parameter / result blocks and ~8 small device arrays per slot cost ~2 ms of it (every hipFree waits for
+// the device).  Streams are handed back only after they have been synchronised.
+struct HostPool {
+  std::mutex mu;
+  std::map<size_t, std::vector<void*>> free_list;
+  void* get(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_list.find(bytes);
+      if (it != free_list.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        return p;
+      }
+    }
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) throw HipError{e, "hipHostMalloc (pool)", __LINE__};
+    return p;
+  }
+  void put(void* p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& v = free_list[bytes];
+    if (v.size() >= 64) { (void)hipHostFree(p); return; }
+    v.push_back(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_list)
+      for (void* p : kv.second) (void)hipHostFree(p);
+    free_list.clear();
+  }
+};
+static HostPool g_host_pool;
+struct StreamPool {
+  std::mutex mu;
+  std::map<int, std::vector<hipStream_t>> free_list;
+  hipStream_t get(int dev) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_list.find(dev);
+      if (it != free_list.end() && !it->second.empty()) {
+        hipStream_t s = it->second.back();
+        it->second.pop_back();
+        return s;
+      }
+    }
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) throw HipError{e, "hipStreamCreateWithFlags (pool)", __LINE__};
+    return s;
+  }
+  void put(int dev, hipStream_t s) {  // the caller has synchronised it
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& v = free_list[dev];
+    if (v.size() >= 64) { (void)hipStreamDestroy(s); return; }
+    v.push_back(s);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& kv : free_list)
+      for (hipStream_t s : kv.second) (void)hipStreamDestroy(s);
+    free_list.clear();
+  }
+};
+static StreamPool g_stream_pool;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -304,6 +375,10 @@ struct Slot {
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
   EvalOut* hOut = nullptr;   // pinned
+  void* small_slab = nullptr;   // one pooled device block behind alpha[2], ldiag, wbuf, part_t, part_g, dP, dOut
+  size_t small_slab_bytes = 0;
+  void* host_slab = nullptr;    // one pooled pinned block behind hP, hOut
+  size_t host_slab_bytes = 0;
   hipGraphExec_t graph[DAG_MAX_VARIANTS + 1][2][2] = {};  // [task-queue variant][target][want_grad]
   // capture state (fit.rs:116-125)
   int best_idx = -1;  // which ping-pong buffer holds the best evaluation so far
@@ -363,6 +438,7 @@ struct Problem : ProblemBase {
   bool refine_ = false;
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
+  bool small_ = false;                      // np = 128, d <= 32: one evaluation = ONE launch (small_eval_kernel), everything in the LDS
   bool like_fit_ = false;                   // path selection of a fit (task queue from 8 blocks on) although there is one slot
   int leaf_dbg_ = 0;                        // HBEGP_LEAF_DBG: debug bits of the diagonal-block kernel (16: helper waves start late)
 
@@ -389,6 +465,10 @@ struct Problem : ProblemBase {
     // 1.3x on alpha / K^-1 for 26 % more time (measured), for kernel matrices beyond cond ~1e5
     refine_ = is_f32 && env_int("HBEGP_F32_REFINE", 0) != 0;
     leaf_dbg_ = env_int("HBEGP_LEAF_DBG", 0) & 16;  // tests only; the bits that skip work stay with tools/leaf_bench
+    // The reference's own regime (minimize.rs:118-120: n stays at 100-200): up to 128 rows the five launches of the general path
+    // cost more in launch gaps and HBM round trips than in arithmetic; one workgroup does the whole evaluation in its LDS
+    // instead (HBEGP_SMALL=0: the general path, which the tests compare it with).
+    small_ = np == NB && d <= SMALL_EVAL_MAXD && !refine_ && env_int("HBEGP_SMALL", 1) != 0;
     const size_t nn = (size_t)np * np;
     Xd.assign(c->devs.size(), nullptr);
     yd.assign(c->devs.size(), nullptr);
@@ -403,36 +483,50 @@ struct Problem : ProblemBase {
       slots[di].resize(n_slots);
       for (auto& s : slots[di]) {
         s.dev = c->devs[di];
-        HIPCHECK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        s.stream = g_stream_pool.get(s.dev);
         bool fresh1 = false, fresh2 = false, fk = false;
         s.W1 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh1));
         s.W2 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh2));
-        for (int b = 0; b < 2; ++b) {
-          s.Kinv[b] = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fk));
-          HIPCHECK(hipMalloc(&s.alpha[b], sizeof(T) * np));
-        }
+        for (int b = 0; b < 2; ++b) s.Kinv[b] = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fk));
         // W2 carries the triangular operand X = L^-1.  The GEMM loader does not mask: the strict upper triangle of W2 must
         // BE zero (tiles on the diagonal are loaded whole).  Nothing in the engine writes there, so clearing the buffer
         // once per slot is enough -- also when it is recycled from the pool (it may have held a full symmetric K^-1).
         // W1's strict upper part is only ever multiplied by those zeros or ignored: it just has to be finite.
-        HIPCHECK(hipMemset(s.W2, 0, sizeof(T) * nn));
+        HIPCHECK(hipMemsetAsync(s.W2, 0, sizeof(T) * nn, nullptr));
         if (refine_) {
           bool f3 = false;
           s.W3 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &f3));
-          HIPCHECK(hipMemset(s.W3, 0, sizeof(T) * nn));  // strict upper triangle must be zero, like W2's
+          HIPCHECK(hipMemsetAsync(s.W3, 0, sizeof(T) * nn, nullptr));  // strict upper triangle must be zero, like W2's
         }
         (void)fresh1; (void)fresh2; (void)fk;  // fresh blocks were cleared by the pool
-        HIPCHECK(hipMalloc(&s.ldiag, sizeof(T) * np));
-        HIPCHECK(hipMalloc(&s.wbuf, sizeof(T) * np));
-        HIPCHECK(hipMalloc(&s.part_t, sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64)));
-        HIPCHECK(hipMalloc(&s.part_g, sizeof(double) * gradtrace_part_elems(np, d)));
-        HIPCHECK(hipMalloc(&s.dP, sizeof(EvalParams)));
-        HIPCHECK(hipMalloc(&s.dOut, sizeof(EvalOut)));
-        HIPCHECK(hipMemset(s.dOut, 0, sizeof(EvalOut)));
-        HIPCHECK(hipHostMalloc(&s.hP, sizeof(EvalParams), hipHostMallocDefault));
-        HIPCHECK(hipHostMalloc(&s.hOut, sizeof(EvalOut), hipHostMallocDefault));
-        memset(s.hP, 0, sizeof(EvalParams));
-        memset(s.hOut, 0, sizeof(EvalOut));
+        // the small per-slot arrays: one pooled block
+        {
+          auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+          const size_t b_vec = up(sizeof(T) * np);
+          const size_t b_part_t = up(sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64));
+          const size_t b_part_g = up(sizeof(double) * gradtrace_part_elems(np, d));
+          const size_t b_p = up(sizeof(EvalParams)), b_o = up(sizeof(EvalOut));
+          s.small_slab_bytes = 4 * b_vec + b_part_t + b_part_g + b_p + b_o;
+          bool fs = false;
+          s.small_slab = g_pool.get(s.dev, s.small_slab_bytes, &fs);
+          char* q = static_cast<char*>(s.small_slab);
+          s.alpha[0] = reinterpret_cast<T*>(q); q += b_vec;
+          s.alpha[1] = reinterpret_cast<T*>(q); q += b_vec;
+          s.ldiag = reinterpret_cast<T*>(q); q += b_vec;
+          s.wbuf = reinterpret_cast<T*>(q); q += b_vec;
+          s.part_t = reinterpret_cast<double*>(q); q += b_part_t;
+          s.part_g = reinterpret_cast<double*>(q); q += b_part_g;
+          s.dP = reinterpret_cast<EvalParams*>(q); q += b_p;
+          s.dOut = reinterpret_cast<EvalOut*>(q);
+          HIPCHECK(hipMemsetAsync(s.dOut, 0, sizeof(EvalOut), nullptr));
+          const size_t h_p = up(sizeof(EvalParams));
+          s.host_slab_bytes = h_p + up(sizeof(EvalOut));
+          s.host_slab = g_host_pool.get(s.host_slab_bytes);
+          s.hP = reinterpret_cast<EvalParams*>(s.host_slab);
+          s.hOut = reinterpret_cast<EvalOut*>(static_cast<char*>(s.host_slab) + h_p);
+          memset(s.hP, 0, sizeof(EvalParams));
+          memset(s.hOut, 0, sizeof(EvalOut));
+        }
       }
       HIPCHECK(hipDeviceSynchronize());
     }
@@ -601,11 +695,11 @@ struct Problem : ProblemBase {
               if (s.graph[v][a][b]) (void)hipGraphExecDestroy(s.graph[v][a][b]);
         const size_t nnb = sizeof(T) * (size_t)np * np;
         g_pool.put(s.dev, s.W1, nnb); g_pool.put(s.dev, s.W2, nnb); g_pool.put(s.dev, s.W3, nnb);
-        for (int b = 0; b < 2; ++b) { g_pool.put(s.dev, s.Kinv[b], nnb); (void)hipFree(s.alpha[b]); }
-        (void)hipFree(s.ldiag); (void)hipFree(s.wbuf); (void)hipFree(s.part_t); (void)hipFree(s.part_g);
-        (void)hipFree(s.dP); (void)hipFree(s.dOut); (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace);
-        (void)hipHostFree(s.hP); (void)hipHostFree(s.hOut);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+        for (int b = 0; b < 2; ++b) g_pool.put(s.dev, s.Kinv[b], nnb);
+        g_pool.put(s.dev, s.small_slab, s.small_slab_bytes);
+        g_host_pool.put(s.host_slab, s.host_slab_bytes);
+        (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace);
+        g_stream_pool.put(s.dev, s.stream);  // synchronised above
       }
       (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
       for (auto& var : dag_var)
@@ -858,11 +952,33 @@ struct Problem : ProblemBase {
     }
   }
 
+  void small_eval(Slot<T>& s, size_t di, int target, int mode) {
+    SmallEval g{};
+    g.X = Xd[di]; g.y = yd[di]; g.n = n; g.d = d; g.P = s.dP;
+    g.W2 = s.W2; g.ldiag = s.ldiag; g.Kinv = s.Kinv[target]; g.alpha = s.alpha[target]; g.out = s.dOut; g.mode = mode;
+    // The kernel reads the parameters from, and writes its few scalar results to, the slot's pinned host blocks itself: the
+    // captured graph of an evaluation is ONE node (no parameter copy, no reset kernel, no result copy -- each was ~2-5 us of
+    // a 57 us evaluation).  HBEGP_SMALL_HOSTIO=0: through device memory and copy nodes, as the general path does.
+    static const bool hostio = env_int("HBEGP_SMALL_HOSTIO", 1) != 0;
+    if (hostio) { g.P = s.hP; g.hout = s.hOut; }
+    else { g.hout = s.dOut; HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream)); }
+    launch_small_eval<T>(g, nu2, s.stream);
+    if (!hostio) HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+  }
+
   void enqueue_eval(Slot<T>& s, size_t di, int target, bool want_grad, PhaseTimer* tm) {
     const int nb = np / NB;
     s.gemm_ord = 0;
     const int* info = &s.dOut->info;
     const bool in_queue = dag_ && dag_full_ && !adhoc_;  // kmat and alpha / lml run as tasks of the factorisation's queue
+    if (small_) {
+      if (dry_) return;
+      if (tm) tm->begin(PhaseTimer::LEAF);
+      small_eval(s, di, target, 1 | 2 | (want_grad ? 4 : 0));
+      if (tm) tm->end();
+      CHECK_LAUNCHES();
+      return;
+    }
     if (!dry_) {
       HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
       launch_reset_out(s.dOut, s.stream);
@@ -912,6 +1028,12 @@ struct Problem : ProblemBase {
     HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
     launch_reset_out(s.dOut, s.stream);
     s.dag_kinv = nullptr;  // the captured K^-1 stays as it is
+    if (small_) {
+      small_eval(s, di, 0, 0);  // factor + inverse factor only: alpha and K^-1 of the captured evaluation stay as they are
+      CHECK_LAUNCHES();
+      HIPCHECK(hipStreamSynchronize(s.stream));
+      return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
+    }
     if (dag_ && dag_full_ && !adhoc_) {
       // the queue also carries the alpha / lml tasks: let them write the alpha buffer that does NOT hold the captured best
       s.dag_target = s.best_idx < 0 ? 1 - s.last_target : 1 - s.best_idx;
@@ -1445,6 +1567,14 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   for (int r = 0; r < nruns; ++r) runs_on[r % ndev]++;
   int n_slots = 1;
   for (int di = 0; di < ndev; ++di) n_slots = std::max(n_slots, std::min(runs_on[di], max_conc));
+  // Up to 128 rows an optimiser run is ONE persistent launch on ONE compute unit (small_fit_kernel: evaluation + L-BFGS step +
+  // capture on the device): every run gets a slot of its own and all of them run side by side
+  constexpr int SMALL_FIT_MAX_RUNS = 64;  // per device
+  bool small_fit = round_up(n, NB) == NB && d <= SMALL_EVAL_MAXD && env_int("HBEGP_SMALL", 1) != 0 && env_int("HBEGP_SMALL_FIT", 1) != 0 &&
+                   !(sizeof(T) == 4 && env_int("HBEGP_F32_REFINE", 0) != 0);
+  for (int di = 0; di < ndev; ++di) small_fit = small_fit && runs_on[di] <= SMALL_FIT_MAX_RUNS;
+  if (small_fit)
+    for (int di = 0; di < ndev; ++di) n_slots = std::max(n_slots, runs_on[di]);
   static const int timing = env_int("HBEGP_TIMING", 0);
   const auto tf0 = std::chrono::steady_clock::now();
   // like_fit: the evaluation path (launches / task queue) is a function of n alone, also for a fit with one slot per device
@@ -1463,6 +1593,100 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   std::string err;
   std::mutex err_mu;
 
+  if (small_fit && prob.small_) {
+    struct RunWs {
+      int di = 0, si = 0, run = 0;
+      LbfgsState* st = nullptr;
+      SmallFitResult* res = nullptr;
+      double *x0 = nullptr, *tr_theta = nullptr, *tr_lml = nullptr, *tr_grad = nullptr;
+    };
+    const int cap = opt.trace_cap > 0 ? opt.maxeval : 0;  // per run; the merged trace is cut at opt.trace_cap below
+    std::vector<RunWs> ws(nruns);
+    auto free_all = [&]() {
+      for (auto& w : ws) {
+        (void)hipSetDevice(ctx->devs[w.di]);
+        (void)hipFree(w.tr_theta); (void)hipFree(w.tr_lml); (void)hipFree(w.tr_grad);
+      }
+    };
+    try {
+      std::vector<int> next_slot(ndev, 0);
+      for (int r = 0; r < nruns; ++r) {
+        RunWs& w = ws[r];
+        w.di = r % ndev; w.si = next_slot[w.di]++; w.run = r;
+        HIPCHECK(hipSetDevice(ctx->devs[w.di]));
+        Slot<T>& s = prob.slots[w.di][w.si];
+        // the run's workspace: the slot's W1 (the kernel matrix never leaves the LDS on this path, so the buffer is free) --
+        // a hipMalloc / hipFree pair per array cost more than the run's arithmetic
+        static_assert(sizeof(LbfgsState) + sizeof(SmallFitResult) + 3 * MAXP * sizeof(double) + 64 <= (size_t)NB * NB * sizeof(float),
+                      "the run's workspace fits the slot's W1");
+        char* base = reinterpret_cast<char*>(s.W1);
+        w.st = reinterpret_cast<LbfgsState*>(base);
+        w.res = reinterpret_cast<SmallFitResult*>(base + (sizeof(LbfgsState) + 15) / 16 * 16);
+        w.x0 = reinterpret_cast<double*>(reinterpret_cast<char*>(w.res) + (sizeof(SmallFitResult) + 15) / 16 * 16);
+        if (cap > 0) {
+          HIPCHECK(hipMalloc(&w.tr_theta, sizeof(double) * (size_t)cap * p));
+          HIPCHECK(hipMalloc(&w.tr_lml, sizeof(double) * cap));
+          HIPCHECK(hipMalloc(&w.tr_grad, sizeof(double) * (size_t)cap * p));
+        }
+        const double* start = r == 0 ? theta0 : starts + (size_t)(r - 1) * p;
+        std::vector<double> box(3 * (size_t)p);  // start point, lower and upper bounds: one copy
+        memcpy(box.data(), start, sizeof(double) * p);
+        memcpy(box.data() + p, lo, sizeof(double) * p);
+        memcpy(box.data() + 2 * p, hi, sizeof(double) * p);
+        HIPCHECK(hipMemcpy(w.x0, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice));
+        SmallFit f{};
+        f.ev.X = prob.Xd[w.di]; f.ev.y = prob.yd[w.di]; f.ev.n = n; f.ev.d = d; f.ev.P = s.dP;
+        f.ev.W2 = s.W2; f.ev.ldiag = s.ldiag; f.ev.out = s.dOut; f.ev.hout = s.dOut;
+        f.Kinv[0] = s.Kinv[0]; f.Kinv[1] = s.Kinv[1]; f.alpha[0] = s.alpha[0]; f.alpha[1] = s.alpha[1];
+        f.st = w.st; f.x0 = w.x0; f.lo = w.x0 + p; f.hi = w.x0 + 2 * p;
+        LbfgsOptions lo_opt;
+        f.maxeval = opt.maxeval; f.memory = opt.lbfgs_memory > 0 ? opt.lbfgs_memory : lo_opt.memory; f.fixed_work = opt.fixed_work != 0;
+        f.pgtol = lo_opt.pgtol; f.ftol = lo_opt.ftol;
+        f.res = w.res; f.trace_theta = w.tr_theta; f.trace_lml = w.tr_lml; f.trace_grad = w.tr_grad; f.trace_cap = cap;
+        launch_small_fit<T>(f, prob.nu2, s.stream);
+        CHECK_LAUNCHES();
+      }
+      int total_evals = 0, total_not_pd = 0, trace_n = 0;
+      for (int r = 0; r < nruns; ++r) {
+        RunWs& w = ws[r];
+        HIPCHECK(hipSetDevice(ctx->devs[w.di]));
+        Slot<T>& s = prob.slots[w.di][w.si];
+        HIPCHECK(hipStreamSynchronize(s.stream));
+        SmallFitResult hr;
+        HIPCHECK(hipMemcpy(&hr, w.res, sizeof(hr), hipMemcpyDeviceToHost));
+        total_evals += hr.n_evals;
+        total_not_pd += hr.n_not_pd;
+        s.best_idx = hr.best_idx;
+        s.best_lml = hr.best_lml;
+        s.best_run = r;
+        s.best_eval = hr.best_eval;
+        s.best_theta.assign(hr.best_theta, hr.best_theta + p);
+        s.last_target = hr.best_idx < 0 ? 0 : hr.best_idx;
+        if (cap > 0 && trace_n < opt.trace_cap) {  // the trace, run by run
+          const int take = std::min(std::min(hr.n_evals, cap), opt.trace_cap - trace_n);
+          if (opt.trace_theta) HIPCHECK(hipMemcpy(opt.trace_theta + (size_t)trace_n * p, w.tr_theta, sizeof(double) * (size_t)take * p, hipMemcpyDeviceToHost));
+          if (opt.trace_lml) HIPCHECK(hipMemcpy(opt.trace_lml + trace_n, w.tr_lml, sizeof(double) * take, hipMemcpyDeviceToHost));
+          if (opt.trace_grad) HIPCHECK(hipMemcpy(opt.trace_grad + (size_t)trace_n * p, w.tr_grad, sizeof(double) * (size_t)take * p, hipMemcpyDeviceToHost));
+          if (opt.trace_run) for (int e = 0; e < take; ++e) opt.trace_run[trace_n + e] = r;
+          trace_n += take;
+        }
+      }
+      if (opt.trace_count) *opt.trace_count = trace_n;
+      if (opt.n_evals) *opt.n_evals = total_evals;
+      if (opt.n_not_pd) *opt.n_not_pd = total_not_pd;
+      n_evals.store(total_evals);
+    } catch (...) {
+      for (auto& w : ws) {  // let the launched kernels finish before their workspaces go
+        if (w.di < (int)prob.slots.size() && w.si < (int)prob.slots[w.di].size()) {
+          (void)hipSetDevice(ctx->devs[w.di]);
+          (void)hipStreamSynchronize(prob.slots[w.di][w.si].stream);
+        }
+      }
+      free_all();
+      throw;
+    }
+    free_all();
+  } else {
   // how many slots of each device are inside an optimiser run: the task-queue launches are sized for that (Problem::DagVariant)
   if (prob.busy_slots_)
     for (int di = 0; di < ndev; ++di) prob.busy_slots_[di].store(std::min(runs_on[di], max_conc));
@@ -1560,6 +1784,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   if (opt.n_evals) *opt.n_evals = n_evals.load();
   if (opt.n_not_pd) *opt.n_not_pd = n_not_pd.load();
   if (!err.empty()) return fail(HBEGP_EHIP, "%s", err.c_str());
+  }  // host-driven optimiser runs
 
   // global arg-max over the per-slot captures, ties -> lowest (run, eval)
   int bdi = -1, bsi = -1;
@@ -1729,7 +1954,11 @@ int hbegp_ctx_create(int n_devices, const int* device_ids, hbegp_ctx** out) {
 void hbegp_ctx_destroy(hbegp_ctx* ctx) {
   if (!ctx) return;
   delete ctx;
-  if (g_live_ctx.fetch_sub(1) == 1) g_pool.trim();
+  if (g_live_ctx.fetch_sub(1) == 1) {
+    g_pool.trim();
+    g_host_pool.trim();
+    g_stream_pool.trim();
+  }
 }
 
 int hbegp_problem_create_f64(hbegp_ctx* ctx, const double* X, const double* y, int n, int d, double nu, int n_slots,

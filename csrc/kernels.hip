@@ -24,6 +24,7 @@
 
 #include "engine.hpp"
 #include "fastmath.hpp"
+#include "lbfgs_step.hpp"
 
 namespace hbegp {
 
@@ -689,7 +690,9 @@ __device__ __forceinline__ void gstore(TIO* p, TIO v) {
   else *p = v;
 }
 
-template <typename T, typename TIO, bool SC1>
+// FROM_LDS: the block image is in the LDS already (lower 16x16 blocks valid, strict upper blocks zero; the caller has met at a
+// barrier): small_eval_kernel assembles the kernel matrix there and never writes it to HBM.
+template <typename T, typename TIO, bool SC1, bool FROM_LDS = false>
 __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict__ W2, int ld, int blk,
                                           TIO* __restrict__ ldiag, int* info, int dbg, char* smem_raw,
                                           TIO* __restrict__ W3 = nullptr) {
@@ -720,7 +723,7 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
   // Load the lower 16x16 blocks of the block; the strict upper blocks start as zeros (they will hold the sums S^T of the
   // inverse).  Wave w takes block row w (rows 16w .. 16w+15, four threads per row): the trip count is wave-uniform, and all
   // loads of a thread are issued before its first LDS store.
-  {
+  if constexpr (!FROM_LDS) {
     const int r = t >> 2, sub = t & 3;           // row, position among the row's four threads
     constexpr int CPR = 16 / VEC;                // 16-byte chunks per 16 columns
     const int nch = (wave + 1) * CPR / 4;        // chunks of this thread: columns [0, 16 (wave + 1)) of its row, interleaved by 4
@@ -739,7 +742,8 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
   }
   // the first diagonal 16x16 block once more, into Sc: the helper wave takes the pivot rows from there (see the elimination)
   if (t < 256) {
-    Sc[(t >> 4) * YS + (t & 15)] = (T)Ablk[(size_t)(t >> 4) * ld + (t & 15)];
+    if constexpr (FROM_LDS) Sc[(t >> 4) * YS + (t & 15)] = As[(t >> 4) * S + (t & 15)];
+    else Sc[(t >> 4) * YS + (t & 15)] = (T)Ablk[(size_t)(t >> 4) * ld + (t & 15)];
   } else {
     for (int e = t - 256; e < 17 * 16; e += 256) Id[(e >> 4) * YS + (e & 15)] = ((e >> 4) == (e & 15)) ? T(1) : T(0);
     if (t < 256 + 16) pool[t - 256] = 0;  // the F flags
@@ -1000,6 +1004,7 @@ __device__ __forceinline__ void leaf_body(TIO* __restrict__ W1, TIO* __restrict_
     gstore<SC1>(&ldiag[blk * NB + t], (TIO)dv0);
     gstore<SC1>(&ldiag[blk * NB + 64 + t], (TIO)dv1);
     const unsigned long long bad0 = __ballot(!(dv0 > T(0))), bad1 = __ballot(!(dv1 > T(0)));
+    if (t == 0) pool[15] = (bad0 | bad1) != 0ull ? 1 : 0;  // small_eval_kernel reads it behind its next barrier
     if ((bad0 | bad1) != 0ull && t == 0) {
       const int first = bad0 != 0ull ? (int)__builtin_ctzll(bad0) : 64 + (int)__builtin_ctzll(bad1);
       atomicCAS(info, 0, 1 + blk * NB + (first & ~15));  // reported per 16-column panel, as rounds 1-3 did
@@ -1717,6 +1722,750 @@ template void launch_predict_small<double>(const double*, int, const double*, in
 template void launch_predict_small<float>(const float*, int, const float*, int, int, int, int, const EvalParams*, const float*, const float*,
                                           float*, double*, double*, int, float*, float*, int*, hipStream_t);
 
+// =================================================================================================================
+// One evaluation in ONE launch for problems of at most 128 rows (np = 128, d <= 32): the reference's own regime
+// (minimize.rs:118-120 keeps n at 100-200).  The five launches of the general path (kmat, diagonal block, trmv x2 + reductions,
+// K^-1 = X^T X, gradient) cost ~2 us of launch gap and one HBM round trip each -- more than their arithmetic at this size.
+// Here one workgroup keeps everything in the LDS:
+//   K = c Matern + s2 I      into the block image (the arithmetic of kmat_kernel, entry for entry; K never goes to HBM)
+//   L, X = L^-1              leaf_body on that image (X and diag(L) also go to HBM: the model keeps them)
+//   alpha = X^T (X y), lml   fp64 dot products against the image (X lives transposed in its strict upper blocks)
+//   K^-1 = X^T X             120 16x16x16 products on MFMA, into the lower blocks of the image (L is no longer needed) and to HBM
+//   g_j = 1/2 sum (alpha alpha^T - K^-1) o dK_j    the arithmetic of gradtrace_kernel, K^-1 and alpha read from the LDS
+// =================================================================================================================
+template <typename TIO, int NU2>
+__device__ __forceinline__ void small_eval_body(const SmallEval& g, char* smem_raw) {
+  using T = double;
+  using C = Cfg<T>;
+  using L = LeafGeom<T>;
+  using acc_t = typename C::acc_t;
+  constexpr int S = L::S, YS = L::YS, YB = L::YB;
+  T* As = reinterpret_cast<T*>(smem_raw);
+  T* Yt = As + 128 * S;
+  T* Sc = Yt + 16 * S;       // the diagonal block's scratch region (pivot-block copy, identity, flags, item tables): 1280 doubles,
+                             // and 480 more to the end of the CU's LDS.  Outside leaf_body it is this kernel's scratch:
+  T* yv = Sc;                //   [128] y
+  T* wv = Sc + 128;          //   [128] w = X y
+  T* av = Sc + 256;          //   [128] alpha (rounded to the element type, as the general path stores it)
+  T* red = Sc + 384;         //   [8 x 35] per-wave partial sums
+  T* ellv = Sc + 664;        //   [32] length scales, then [32] their inverse squares (in the element type's arithmetic)
+  T* feat = Sc + 728;        //   [8][128] a chunk of eight features of all rows, [feature][row]; 8 doubles to the end of the CU's LDS stay free
+                             //   (small_fit_kernel keeps two flags there)
+  static_assert(728 + 8 * 128 + 8 <= (163840 - (128 * S + 16 * S) * 8) / 8, "the scratch of small_eval_kernel fits behind the block image");
+  int* pool = reinterpret_cast<int*>(Sc + YB + 17 * YS + 2);  // leaf_body's flags (pool[15]: not positive definite)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int m16 = lane & 15, q4 = lane >> 4;
+  const int n = g.n, d = g.d;
+  const TIO* X = static_cast<const TIO*>(g.X);
+  const EvalParams* P = g.P;
+  // the parameters are read with agent-scope loads: inside small_fit_kernel they change between two evaluations of ONE launch,
+  // and a scalar load (what a uniform address compiles to) goes through the scalar cache, which no vector store updates
+  auto pld = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const TIO amp = (TIO)pld(&P->amp), noise = (TIO)pld(&P->noise);
+  if (t == 0) g_leaf_stamps[200] = (long long)__builtin_readcyclecounter();
+  // start of an evaluation (what launch_reset_out does for the general path): the outputs are poisoned, the flags cleared
+  EvalOut* out = g.hout;
+  {
+    const double poison = __longlong_as_double(0x7ff8000000005eedLL);
+    if (t < MAXP) out->grad[t] = poison;
+    if (t == 0) {
+      out->lml = poison; out->yalpha = poison; out->logdet = poison;
+      out->info = 0; out->n_warn = 0; out->done = 0;
+      g.out->info = 0;
+    }
+  }
+  // thread (tx, ty, half) owns, in each of the three lower 64x64 tiles (0,0), (1,0), (1,1): rows ty + 16 (2 half + r), r = 0, 1,
+  // columns 4 tx .. 4 tx + 3 -- per entry the sums of kmat_kernel / gradtrace_kernel in their order
+  const int tx = t & 15, ty = (t >> 4) & 15, half = t >> 8;
+  auto tile_i0 = [](int tile) { return tile == 0 ? 0 : 64; };
+  auto tile_j0 = [](int tile) { return tile == 2 ? 64 : 0; };
+  // eight features of all 128 rows -> feat[u][row]; scaled: divided by the length scale (kmat), else raw (gradient)
+  auto stage_features = [&](int kc, bool scaled) {
+    for (int e = t; e < 8 * 128; e += 512) {
+      const int row = e >> 3, u = e & 7, k = kc + u;
+      TIO v = TIO(0);
+      if (row < n && k < d) {
+        v = X[(size_t)row * d + k];
+        if (scaled) v = v / (TIO)ellv[k];  // matern_kernel.rs:51-60
+      }
+      feat[u * 128 + row] = (T)v;
+    }
+  };
+  if (t < 32) {
+    const TIO ell = t < d ? (TIO)pld(&P->ell[t]) : TIO(1);  // A::from_f (matern_kernel.rs:50)
+    ellv[t] = (T)ell;
+    ellv[32 + t] = (T)(TIO(1) / (ell * ell));          // 1/scales_k_square (matern_kernel.rs:94-98)
+  }
+  __syncthreads();
+
+  // ---- K into the image (never to HBM): squared scaled distances accumulated feature by feature, eight features per staging
+  {
+    TIO acc[3][2][4];
+#pragma unroll
+    for (int tile = 0; tile < 3; ++tile)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[tile][r][c] = TIO(0);
+    for (int kc = 0; kc < d; kc += 8) {
+      stage_features(kc, true);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kc + u < d) {  // uniform; cdist accumulation order (matern_kernel.rs:274-278)
+#pragma unroll
+          for (int tile = 0; tile < 3; ++tile) {
+            TIO a[2], b[4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) a[r] = (TIO)feat[u * 128 + tile_i0(tile) + ty + 16 * (2 * half + r)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = (TIO)feat[u * 128 + tile_j0(tile) + tx * 4 + c];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const TIO df = a[r] - b[c];
+                acc[tile][r][c] += df * df;
+              }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // zeros everywhere first (the strict upper 16x16 blocks must start as zeros), then the three tiles' entries
+    for (int e = t; e < 128 * (S / 2); e += 512) reinterpret_cast<d2*>(As)[e] = d2{0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int tile = 0; tile < 3; ++tile)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int gi = tile_i0(tile) + ty + 16 * (2 * half + r);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gj = tile_j0(tile) + tx * 4 + c;
+          if ((gj >> 4) <= (gi >> 4)) {  // lower 16x16 blocks only
+            const TIO v = kmat_entry<TIO>(acc[tile][r][c], NU2, amp, noise, gi == gj);
+            As[gi * S + gj] = (T)((gi < n && gj < n) ? v : ((gi == gj) ? TIO(1) : TIO(0)));  // identity padding
+          }
+        }
+      }
+    __syncthreads();
+  }
+  if (t == 0) g_leaf_stamps[201] = (long long)__builtin_readcyclecounter();
+
+  // ---- L and X = L^-1
+  TIO* W2 = static_cast<TIO*>(g.W2);
+  leaf_body<T, TIO, false, true>(nullptr, W2, 128, 0, static_cast<TIO*>(g.ldiag), &g.out->info, 0, smem_raw, nullptr);
+  __syncthreads();
+  if (t == 0) g_leaf_stamps[202] = (long long)__builtin_readcyclecounter();
+  if (pool[15] != 0) {  // not positive definite: the outputs stay poisoned (lml.rs:47-50)
+    if (t == 0) out->info = g.out->info;
+    return;
+  }
+  if (!(g.mode & 1)) return;
+  __syncthreads();  // every thread has read the flag: the scratch may be reused
+
+  // X[i][k] (i >= k) in the image: block (I, K), I > K, lives transposed in block (K, I); the diagonal blocks in Yt (transposed)
+  auto xel = [&](int i, int k) -> T {
+    const int I = i >> 4, K = k >> 4;
+    return I > K ? As[(K * 16 + (k & 15)) * S + I * 16 + (i & 15)] : Yt[(k & 15) * S + 16 * I + (i & 15)];
+  };
+  if (t < 128) yv[t] = t < n ? (T)static_cast<const TIO*>(g.y)[t] : T(0);
+  if (t >= 128 && t < 160) {  // the length scales again (leaf_body's scratch went over them)
+    const int k = t - 128;
+    const TIO ell = k < d ? (TIO)pld(&P->ell[k]) : TIO(1);
+    ellv[k] = (T)ell;
+    ellv[32 + k] = (T)(TIO(1) / (ell * ell));
+  }
+  __syncthreads();
+  {
+    // w_i = sum_{k <= i} X[i][k] y[k]: four threads per row, fp64, four independent partial sums per thread
+    const int i = t >> 2, sub = t & 3;
+    T acc[4] = {0, 0, 0, 0};
+    int k = sub;
+    for (; k + 12 <= i; k += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = __builtin_fma(xel(i, k + 4 * u), yv[k + 4 * u], acc[u]);
+    }
+    for (; k <= i; k += 4) acc[0] = __builtin_fma(xel(i, k), yv[k], acc[0]);
+    T a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (sub == 0) wv[i] = (T)(TIO)a;  // the general path keeps w in the element type
+  }
+  __syncthreads();
+  {
+    // alpha_j = sum_{i >= j} X[i][j] w_i
+    const int j = t >> 2, sub = t & 3;
+    T acc[4] = {0, 0, 0, 0};
+    int i = j + sub;
+    for (; i + 12 < 128; i += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = __builtin_fma(xel(i + 4 * u, j), wv[i + 4 * u], acc[u]);
+    }
+    for (; i < 128; i += 4) acc[0] = __builtin_fma(xel(i, j), wv[i], acc[0]);
+    T a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (sub == 0) {
+      const TIO at = j < n ? (TIO)a : TIO(0);
+      static_cast<TIO*>(g.alpha)[j] = at;
+      av[j] = (T)at;
+    }
+  }
+  __syncthreads();
+  {
+    // lml = -1/2 y^T alpha - sum log L_ii - n/2 log 2 pi (lml.rs:57-59)
+    T ya = 0, ld = 0;
+    if (t < n) {
+      ya = yv[t] * av[t];
+      ld = log((T)(TIO)As[t * S + t]);
+    }
+    ya = wave_sum(ya);
+    ld = wave_sum(ld);
+    if (lane == 0) { red[wave * 2] = ya; red[wave * 2 + 1] = ld; }
+    __syncthreads();
+    if (t == 0) {
+      T s1 = 0, s2 = 0;
+      for (int w = 0; w < 8; ++w) { s1 += red[2 * w]; s2 += red[2 * w + 1]; }
+      out->yalpha = s1;
+      out->logdet = s2;
+      out->lml = __builtin_fma(-0.5, s1, -s2) - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
+      out->done = 1;  // one writer
+    }
+  }
+  if (t == 0) g_leaf_stamps[203] = (long long)__builtin_readcyclecounter();
+  if (!(g.mode & 2)) return;
+
+  // ---- K^-1 = X^T X, lower blocks (I, J): sum_{K >= I} X[K,I]^T X[K,J].  Both operands are rows of the image in the layout an
+  // MFMA fragment wants (X[K,I]^T = block (I,K) of the image, or Yt_I for K = I).  36 blocks, 120 products, dealt to the 8 waves.
+  {
+    const int P0 = (m16 * S + q4) * (int)sizeof(T), P1 = (q4 * S + m16) * (int)sizeof(T);
+    char* lds0 = reinterpret_cast<char*>(As);
+    auto ldsT = [&](int byte_off) -> T& { return *reinterpret_cast<T*>(lds0 + byte_off); };
+    TIO* Kinv = static_cast<TIO*>(g.Kinv);
+    int q = 0;
+    for (int I = 0; I < 8; ++I)
+      for (int J = 0; J <= I; ++J, ++q) {
+        if ((q & 7) != wave) continue;
+        acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        for (int K = I; K < 8; ++K) {
+          const int pa = (K == I ? (int)leaf_yt_bytes(I) : (int)leaf_blk_bytes(I, K)) + P0;
+          const int pb = (K == J ? (int)leaf_yt_bytes(J) : (int)leaf_blk_bytes(J, K)) + P0;
+          T af[4], bf[4];
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            af[k4] = ldsT(pa + k4 * 32);
+            bf[k4] = ldsT(pb + k4 * 32);
+          }
+          a0 = C::mfma(af[0], bf[0], a0);
+          a1 = C::mfma(af[2], bf[2], a1);
+          a0 = C::mfma(af[1], bf[1], a0);
+          a1 = C::mfma(af[3], bf[3], a1);
+        }
+        const int pc = (int)leaf_blk_bytes(I, J) + P1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const T v = a0[r] + a1[r];
+          ldsT(pc + r * 4 * S * (int)sizeof(T)) = v;  // over L: nobody reads the factor any more
+          Kinv[(size_t)(I * 16 + q4 + 4 * r) * 128 + J * 16 + m16] = (TIO)v;
+        }
+      }
+  }
+  if (!(g.mode & 4)) return;
+  __syncthreads();
+  if (t == 0) g_leaf_stamps[204] = (long long)__builtin_readcyclecounter();
+
+  // ---- gradient (lml.rs:62-70): the arithmetic of gradtrace_kernel on the three lower 64x64 tiles; K^-1 and alpha come from the
+  // LDS, the raw features are staged eight at a time
+  {
+    const int p = d + 2;
+    double gsum[2] = {0, 0};          // noise, amplitude
+    TIO coef[3][2][4], dsum[3][2][4];
+#pragma unroll
+    for (int tile = 0; tile < 3; ++tile)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dsum[tile][r][c] = TIO(0);
+    // pass A: scaled squared distances (matern_kernel.rs:94-98 form), then per entry the coefficient wgt * W * c * g(r)
+    for (int kc = 0; kc < d; kc += 8) {
+      stage_features(kc, false);
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kc + u < d) {
+          const TIO il2 = (TIO)ellv[32 + kc + u];
+#pragma unroll
+          for (int tile = 0; tile < 3; ++tile) {
+            TIO a[2], b[4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) a[r] = (TIO)feat[u * 128 + tile_i0(tile) + ty + 16 * (2 * half + r)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = (TIO)feat[u * 128 + tile_j0(tile) + tx * 4 + c];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const TIO df = a[r] - b[c];
+                dsum[tile][r][c] += df * df * il2;
+              }
+          }
+        }
+      }
+      if (kc + 8 < d) __syncthreads();  // the last chunk stays staged: pass B starts with it when d <= 8
+    }
+#pragma unroll
+    for (int tile = 0; tile < 3; ++tile)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int gi = tile_i0(tile) + ty + 16 * (2 * half + r);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gj = tile_j0(tile) + tx * 4 + c;
+          TIO cf = TIO(0);
+          if (gi < n && gj <= gi) {
+#pragma clang fp contract(off)
+            const TIO w = (TIO)av[gi] * (TIO)av[gj] - (TIO)As[gi * S + gj];  // lml.rs:62 (tmp)
+            const TIO wgt = (gi == gj) ? TIO(1) : TIO(2);
+            TIO km, gr;
+            const TIO ds = dsum[tile][r][c];
+            if (NU2 == 5) {
+              const TIO tt = sqrt_nonneg(ds * TIO(5));
+              const TIO e = exp_nonpos(-tt);
+              km = __builtin_fma(tt * tt, TIO(1.0 / 3.0), TIO(1) + tt) * e;
+              gr = TIO(5.0 / 3.0) * (tt + TIO(1)) * e;  // matern_kernel.rs:119-131
+            } else if (NU2 == 3) {
+              const TIO tt = sqrt_nonneg(ds * TIO(3));
+              const TIO e = exp_nonpos(-tt);
+              km = (tt + TIO(1)) * e;
+              gr = TIO(3) * e;  // matern_kernel.rs:112-118
+            } else if (NU2 == 0) {
+              km = exp_nonpos(TIO(-0.5) * ds);
+              gr = km;
+            } else {
+              const TIO rr = sqrt_nonneg(ds);
+              km = exp_nonpos(-rr);
+              gr = (rr > TIO(0)) ? km / rr : TIO(0);  // matern_kernel.rs:102-111
+            }
+            if (gi == gj) gsum[0] += (double)(w * noise);
+            gsum[1] += (double)(wgt * w * (amp * km));
+            cf = wgt * w * amp * gr;
+          }
+          coef[tile][r][c] = cf;
+        }
+      }
+    {
+      const double s0 = wave_sum(gsum[0]), s1 = wave_sum(gsum[1]);
+      if (lane == 0) { red[wave * 35] = s0; red[wave * 35 + 1] = s1; }  // (the lml's sums in red were read before the K^-1 stage's barrier)
+    }
+    // pass B: the length-scale sums, eight parameters per staging
+    const int last_kc = ((d - 1) >> 3) << 3;  // the chunk pass A left staged
+    for (int kc = last_kc; kc >= 0; kc -= 8) {
+      if (kc != last_kc) {
+        __syncthreads();
+        stage_features(kc, false);
+        __syncthreads();
+      }
+      double acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kc + u < d) {
+          const TIO il2 = (TIO)ellv[32 + kc + u];
+          TIO sacc = TIO(0);
+#pragma unroll
+          for (int tile = 0; tile < 3; ++tile) {
+            TIO a[2], b[4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) a[r] = (TIO)feat[u * 128 + tile_i0(tile) + ty + 16 * (2 * half + r)];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = (TIO)feat[u * 128 + tile_j0(tile) + tx * 4 + c];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const TIO df = a[r] - b[c];
+                sacc += coef[tile][r][c] * (df * df * il2);
+              }
+          }
+          acc[u] = (double)sacc;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kc + u < d) {
+          const double sk = wave_sum(acc[u]);
+          if (lane == 0) red[wave * 35 + 2 + kc + u] = sk;
+        }
+      }
+    }
+    __syncthreads();
+    if (t < p) {
+      double sacc = 0;
+      for (int w = 0; w < 8; ++w) sacc += red[w * 35 + t];
+      out->grad[t] = 0.5 * sacc;
+    }
+    __syncthreads();
+    if (t == 0) {
+      __threadfence_system();
+      out->done = 3;
+      g_leaf_stamps[205] = (long long)__builtin_readcyclecounter();
+    }
+  }
+}
+
+template <typename TIO, int NU2>
+__global__ void __launch_bounds__(512, 2) small_eval_kernel(SmallEval g) {
+  extern __shared__ __align__(16) char smem_raw[];
+  small_eval_body<TIO, NU2>(g, smem_raw);
+}
+
+// ---- the bounded L-BFGS step of lbfgs_step.hpp, one wavefront wide: lane i owns dimension i (the GP has at most 34 parameters
+// here), a dot product is a reduction across the wave.  Same method, same constants, same decisions, same evaluation counting as
+// lbfgs_begin / lbfgs_advance (which stay the host's implementation and this code's specification: a single thread walking
+// the host form on the device took 70 us per evaluation -- longer than the evaluation -- because every load of the optimiser's
+// state is a dependent round trip); sums run in another order, so iterates agree with the host form to rounding, not bit for
+// bit (tests/test_gpu_fit.py compares the two on the same fits).  The vectors live in the run's LbfgsState in global memory
+// (lane-indexed loads: never the scalar cache), the scalars in the wave's registers.
+struct WaveLbfgs {
+  int phase, nevals, iterations, converged, hcount;
+  double f, step, gs;
+  double rho[LBFGS_MAXM];
+};
+
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum / maximum over the 64 lanes, the result in every lane; fixed order: within quads, octets, rows of 16 (DPP), then the four rows
+__device__ __forceinline__ double wave_allsum(double v) {
+  v += dpp64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp64<0x141>(v);   // row_half_mirror
+  v += dpp64<0x140>(v);   // row_mirror
+  double r = readlane(v, 0);
+  r += readlane(v, 16);
+  r += readlane(v, 32);
+  r += readlane(v, 48);
+  return r;
+}
+__device__ __forceinline__ double wave_allmax(double v) {
+  v = fmax(v, dpp64<0xB1>(v));
+  v = fmax(v, dpp64<0x4E>(v));
+  v = fmax(v, dpp64<0x141>(v));
+  v = fmax(v, dpp64<0x140>(v));
+  return fmax(fmax(readlane(v, 0), readlane(v, 16)), fmax(readlane(v, 32), readlane(v, 48)));
+}
+
+// proposes xn = clip(x + step d) (lane-wise); false: the step no longer changes x
+__device__ __forceinline__ bool wl_propose(WaveLbfgs& w, LbfgsState* st, int i, bool act) {
+  double dx = 0, gsl = 0;
+  if (act) {
+    double v = st->x[i] + w.step * st->d[i];
+    v = fmin(fmax(v, st->lo[i]), st->hi[i]);
+    st->xn[i] = v;
+    dx = v - st->x[i];
+    gsl = st->g[i] * dx;
+  }
+  w.gs = wave_allsum(gsl);
+  return wave_allmax(fabs(dx)) != 0.0;
+}
+
+// start of an outer iteration at (x, f, g): convergence test, search direction, first trial point; returns the next phase
+__device__ __forceinline__ int wl_begin_iteration(WaveLbfgs& w, LbfgsState* st, int i, bool act, int maxeval, double pgtol) {
+  for (int guard = 0; guard < 3; ++guard) {
+    if (w.nevals >= maxeval) return 2;
+    const double xi = act ? st->x[i] : 0.0, gi = act ? st->g[i] : 0.0;
+    const double loi = act ? st->lo[i] : 0.0, hii = act ? st->hi[i] : 0.0;
+    const bool at_lo = xi <= loi && gi > 0, at_hi = xi >= hii && gi < 0;
+    const double pg = (act && !(at_lo || at_hi)) ? gi : 0.0;
+    if (wave_allmax(fabs(pg)) <= pgtol * fmax(1.0, fabs(w.f))) {
+      w.converged = 1;
+      return 2;
+    }
+    // two-loop recursion on the free variables; the history pairs of this lane's dimension are fetched up front (independent
+    // loads: one round trip to the L2 instead of one per pair inside the dependent chain of reductions)
+    double q = pg;
+    double a[LBFGS_MAXM], sh[LBFGS_MAXM], yh[LBFGS_MAXM];
+#pragma unroll
+    for (int h = 0; h < LBFGS_MAXM; ++h) {
+      const bool on = act && h < w.hcount;
+      sh[h] = on ? st->S[h][i] : 0.0;
+      yh[h] = on ? st->Y[h][i] : 0.0;
+    }
+#pragma unroll
+    for (int h = LBFGS_MAXM - 1; h >= 0; --h) {
+      a[h] = 0;
+      if (h < w.hcount) {
+        a[h] = w.rho[h] * wave_allsum(sh[h] * q);
+        q -= a[h] * yh[h];
+      }
+    }
+    double gamma = 1.0;
+    if (w.hcount > 0) {
+      double sl = 0, yl = 0;
+#pragma unroll
+      for (int h = 0; h < LBFGS_MAXM; ++h)
+        if (h == w.hcount - 1) { sl = sh[h]; yl = yh[h]; }
+      const double sy = wave_allsum(sl * yl), yy = wave_allsum(yl * yl);
+      if (yy > 0) gamma = sy / yy;
+    }
+    q *= gamma;
+#pragma unroll
+    for (int h = 0; h < LBFGS_MAXM; ++h) {
+      if (h < w.hcount) {
+        const double bq = w.rho[h] * wave_allsum(yh[h] * q);
+        q += sh[h] * (a[h] - bq);
+      }
+    }
+    double dv = (pg == 0.0) ? 0.0 : -q;
+    double dg = wave_allsum(dv * gi);
+    if (!(dg < 0)) {  // not a descent direction: fall back to projected steepest descent
+      w.hcount = 0;
+      dv = -pg;
+      dg = wave_allsum(dv * gi);
+    }
+    if (act) st->d[i] = dv;
+    w.step = 1.0;
+    if (w.hcount == 0) {
+      const double dn = wave_allsum(dv * dv);
+      w.step = fmin(1.0, 1.0 / sqrt(fmax(dn, 1e-300)));
+    }
+    if (wl_propose(w, st, i, act)) return 1;
+    if (w.hcount > 0) {  // the first step does not move x: retry once from steepest descent with a clean history
+      w.hcount = 0;
+      continue;
+    }
+    return 2;
+  }
+  return 2;
+}
+
+// feeds the evaluation of the requested point (fe, the wave's gradient entry ge); true while another evaluation is wanted
+__device__ __forceinline__ bool wl_advance(WaveLbfgs& w, LbfgsState* st, int i, bool act, double fe, double ge, int maxeval, int m,
+                                           double pgtol, double ftol, bool fixed_work) {
+  ++w.nevals;
+  if (fe != fe) fe = INFINITY;
+  int next = 2;
+  if (w.phase == 0) {
+    w.f = fe;
+    if (act) st->g[i] = ge;
+    next = (fe - fe == 0.0) ? wl_begin_iteration(w, st, i, act, maxeval, pgtol) : 2;
+  } else if (w.phase == 1) {
+    const double fn = fe;
+    if ((fn - fn == 0.0) && fn <= w.f + 1e-4 * w.gs) {
+      ++w.iterations;
+      const double sv = act ? st->xn[i] - st->x[i] : 0.0, yv = act ? ge - st->g[i] : 0.0;
+      const double sy = wave_allsum(sv * yv), ss = wave_allsum(sv * sv), yy = wave_allsum(yv * yv);
+      if (sy > 1e-10 * sqrt(ss * yy) && sy > 0) {
+        if (w.hcount == m) {  // drop the oldest pair
+          for (int h = 1; h < w.hcount; ++h) {
+            if (act) {
+              st->S[h - 1][i] = st->S[h][i];
+              st->Y[h - 1][i] = st->Y[h][i];
+            }
+          }
+#pragma unroll
+          for (int h = 1; h < LBFGS_MAXM; ++h) w.rho[h - 1] = w.rho[h];
+          --w.hcount;
+        }
+        if (act) {
+          st->S[w.hcount][i] = sv;
+          st->Y[w.hcount][i] = yv;
+        }
+#pragma unroll
+        for (int h = 0; h < LBFGS_MAXM; ++h)
+          if (h == w.hcount) w.rho[h] = 1.0 / sy;
+        ++w.hcount;
+      }
+      const double fold = w.f;
+      if (act) {
+        st->x[i] = st->xn[i];
+        st->g[i] = ge;
+      }
+      w.f = fn;
+      if (fold - w.f <= ftol * fmax(1.0, fabs(w.f))) {
+        w.converged = 1;
+        next = 2;
+      } else {
+        next = wl_begin_iteration(w, st, i, act, maxeval, pgtol);
+      }
+    } else {
+      double nstep = 0.5 * w.step;
+      if ((fn - fn == 0.0) && w.gs < 0) {
+        const double denom = 2.0 * (fn - w.f - w.gs);
+        if (denom > 0) nstep = fmin(fmax(-w.gs * w.step / denom, 0.1 * w.step), 0.5 * w.step);
+      }
+      w.step = nstep;
+      const bool again = !(w.step < 1e-20) && w.nevals < maxeval && wl_propose(w, st, i, act);
+      if (again) {
+        next = 1;
+      } else if (w.hcount > 0) {
+        w.hcount = 0;
+        next = w.nevals < maxeval ? wl_begin_iteration(w, st, i, act, maxeval, pgtol) : 2;
+      } else {
+        next = 2;
+      }
+    }
+  }
+  if (next == 1) {
+    w.phase = 1;
+    return true;
+  }
+  if (fixed_work && w.nevals < maxeval) {
+    w.phase = 2;
+    return true;
+  }
+  w.phase = 3;
+  return false;
+}
+
+// out-of-line copy of the evaluation for small_fit_kernel: a register allocation of its own (inlined into the loop the kernel
+// spilled 216 VGPRs)
+template <typename TIO, int NU2>
+__device__ __attribute__((noinline)) void small_eval_call(const SmallEval* g, char* smem_raw) {
+  small_eval_body<TIO, NU2>(*g, smem_raw);
+}
+
+// ---- a whole optimiser run in ONE launch (n <= 128): the evaluation above in a loop, with the bounded L-BFGS step and the fit's
+// objective wrapper (fit.rs:94-133: clamped parameters, failed factorisation -> +inf, capture of the best evaluation) on the
+// device, in wave 0.  The host launches one such kernel per optimiser run (gradmin.rs:19-31: the runs are independent), all
+// side by side, and collects.  The ~40 us round trip through the host per evaluation (graph launch + completion wake-up +
+// three host threads on the runtime's lock) becomes ~5 us of wave-wide vector arithmetic.
+template <typename TIO, int NU2>
+__global__ void __launch_bounds__(512, 2) small_fit_kernel(SmallFit f) {
+  extern __shared__ __align__(16) char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int p = f.ev.d + 2;
+  LbfgsState* st = f.st;
+  int* flags = reinterpret_cast<int*>(smem_raw + 163840 - 64);  // [0] another evaluation is wanted, [1] its ping-pong target
+  SmallFitResult* res = f.res;
+  EvalParams* P = const_cast<EvalParams*>(f.ev.P);
+  const bool act = wave == 0 && lane < p;
+  // wave 0's view of the run (registers: a scalar stored to global memory and re-read through a uniform address could come back
+  // stale from the scalar cache)
+  WaveLbfgs w{};
+  int best_idx = -1, best_eval = 0, n_evals = 0, n_not_pd = 0;
+  double best_lml = -INFINITY;
+  // wave 0: the requested point -> clamped linear-space parameters (fit.rs:94-96; the noise is not clamped, :96)
+  auto publish_request = [&]() {
+    if (act) {
+      const double th = w.phase == 1 ? st->xn[lane] : st->x[lane];
+      double v = exp(th);
+      if (lane >= 1) v = v < f.lo[lane] ? f.lo[lane] : (f.hi[lane] < v ? f.hi[lane] : v);  // bounded_value.rs:43-56
+      if (lane == 0) P->noise = v;
+      else if (lane == 1) P->amp = v;
+      else P->ell[lane - 2] = v;
+    }
+    if (lane == 0) flags[1] = best_idx < 0 ? 0 : 1 - best_idx;  // never overwrite the captured best (fit.rs:116-125)
+    __threadfence();
+  };
+  if (wave == 0) {
+    // log-space box (fit.rs:137-146) and the clipped start point
+    if (act) {
+      const double l = log(f.lo[lane]), h = log(f.hi[lane]);
+      st->lo[lane] = l;
+      st->hi[lane] = h;
+      st->x[lane] = fmin(fmax(f.x0[lane], l), h);
+    }
+    w.phase = 0;
+    w.f = INFINITY;
+    w.step = 1.0;
+    if (lane == 0) flags[0] = 1;
+    publish_request();
+  }
+  __syncthreads();
+  for (int eval_idx = 0; eval_idx < f.maxeval + 1; ++eval_idx) {  // bounded whatever the state machine does
+    const int target = flags[1];
+    __syncthreads();  // the flags sit behind the evaluation's scratch: read before it starts
+    SmallEval g = f.ev;
+    g.Kinv = f.Kinv[target];
+    g.alpha = f.alpha[target];
+    g.mode = 7;
+    small_eval_call<TIO, NU2>(&g, smem_raw);
+    __threadfence();
+    __syncthreads();
+    if (wave == 0) {
+      const EvalOut* out = g.hout;
+      double lml = __hip_atomic_load(&out->lml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      double ge = act ? __hip_atomic_load(&out->grad[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      const int info = __hip_atomic_load(&out->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = info == 0 && (lml - lml == 0.0) && wave_allmax((ge - ge == 0.0) ? 0.0 : 1.0) == 0.0;
+      if (!ok) {  // handled like a failed factorisation (lml.rs:47-50 -> fit.rs:105-112): objective +inf, zero gradient
+        lml = -INFINITY;
+        ge = 0.0;
+        ++n_not_pd;
+      }
+      ++n_evals;
+      const double th = act ? (w.phase == 1 ? st->xn[lane] : st->x[lane]) : 0.0;
+      if (eval_idx < f.trace_cap) {
+        if (act) {
+          f.trace_theta[(size_t)eval_idx * p + lane] = th;
+          f.trace_grad[(size_t)eval_idx * p + lane] = ge;
+        }
+        if (lane == 0) f.trace_lml[eval_idx] = lml;
+      }
+      if (ok && (best_idx < 0 || lml > best_lml)) {  // strictly greater wins; ties keep the earlier evaluation
+        best_idx = target;
+        best_lml = lml;
+        best_eval = eval_idx;
+        if (act) res->best_theta[lane] = th;
+      }
+      // fit.rs:128-133: the optimiser minimises -lml
+      const bool more = wl_advance(w, st, lane, act, ok ? -lml : INFINITY, -ge, f.maxeval, f.memory < 1 ? 1 : (f.memory > LBFGS_MAXM ? LBFGS_MAXM : f.memory),
+                                   f.pgtol, f.ftol, f.fixed_work != 0);
+      if (lane == 0) flags[0] = more ? 1 : 0;
+      if (more) publish_request();
+    }
+    __syncthreads();
+    const int more = flags[0];
+    __syncthreads();
+    if (!more) break;
+  }
+  if (t == 0) {
+    res->best_idx = best_idx;
+    res->best_lml = best_lml;
+    res->best_eval = best_eval;
+    res->n_evals = n_evals;
+    res->n_not_pd = n_not_pd;
+  }
+}
+
+template <typename T>
+void launch_small_fit(const SmallFit& f, int nu2, hipStream_t s) {
+  const dim3 grid(1), block(512);
+  const size_t lds = 163840;  // the whole LDS of a CU
+  switch (nu2) {
+    case 0: hipLaunchKernelGGL((small_fit_kernel<T, 0>), grid, block, lds, s, f); break;
+    case 1: hipLaunchKernelGGL((small_fit_kernel<T, 1>), grid, block, lds, s, f); break;
+    case 3: hipLaunchKernelGGL((small_fit_kernel<T, 3>), grid, block, lds, s, f); break;
+    default: hipLaunchKernelGGL((small_fit_kernel<T, 5>), grid, block, lds, s, f); break;
+  }
+}
+template void launch_small_fit<double>(const SmallFit&, int, hipStream_t);
+template void launch_small_fit<float>(const SmallFit&, int, hipStream_t);
+
+template <typename T>
+void launch_small_eval(const SmallEval& g, int nu2, hipStream_t s) {
+  const dim3 grid(1), block(512);
+  const size_t lds = 163840;  // the whole LDS of a CU: the block image + the kernel's scratch
+  switch (nu2) {
+    case 0: hipLaunchKernelGGL((small_eval_kernel<T, 0>), grid, block, lds, s, g); break;
+    case 1: hipLaunchKernelGGL((small_eval_kernel<T, 1>), grid, block, lds, s, g); break;
+    case 3: hipLaunchKernelGGL((small_eval_kernel<T, 3>), grid, block, lds, s, g); break;
+    default: hipLaunchKernelGGL((small_eval_kernel<T, 5>), grid, block, lds, s, g); break;
+  }
+}
+template void launch_small_eval<double>(const SmallEval&, int, hipStream_t);
+template void launch_small_eval<float>(const SmallEval&, int, hipStream_t);
+
 // Per-device one-time setup: kernels that use more than 64 KiB of dynamic LDS need the attribute raised.  Called from
 // hbegp_ctx_create() for every device, before any stream capture.
 static void init_dag_kernels();  // dag_kernel.inc.hpp (end of this file)
@@ -1735,6 +2484,23 @@ void init_kernels() {
   set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, double>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f64>: dynamic LDS limit");
   set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, float>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f32>: dynamic LDS limit");
   init_dag_kernels();
+  const int lb = 163840;
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 0>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 1>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 3>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 5>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<float, 0>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<float, 1>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<float, 3>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<float, 5>), lb, "small_eval_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<double, 0>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<double, 1>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<double, 3>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<double, 5>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<float, 0>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<float, 1>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<float, 3>), lb, "small_fit_kernel: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&small_fit_kernel<float, 5>), lb, "small_fit_kernel: dynamic LDS limit");
 }
 
 __global__ void set_info_kernel(int* info, int value) { *info = value; }

@@ -13,6 +13,8 @@
 #include <limits>
 #include <vector>
 
+#include "lbfgs_step.hpp"
+
 namespace hbegp {
 
 struct LbfgsOptions {
@@ -33,8 +35,11 @@ struct LbfgsResult {
 // objective(x, grad) -> f ; may return +inf (failed evaluation; grad then ignored)
 using Objective = std::function<double(const double* x, double* grad)>;
 
-inline LbfgsResult lbfgsb_minimize(const Objective& fun, double* x, const double* lo, const double* hi, int n,
-                                   const LbfgsOptions& opt) {
+// The method written as nested loops around the objective: the form the state machine of lbfgs_step.hpp was derived from.  Kept
+// as the reference of tests/cpp/test_lbfgs_step.cpp (the two must produce the same iterates bit for bit); production code
+// calls lbfgsb_minimize() below.
+inline LbfgsResult lbfgsb_minimize_loops(const Objective& fun, double* x, const double* lo, const double* hi, int n,
+                                         const LbfgsOptions& opt) {
   LbfgsResult res;
   const int m = std::max(1, opt.memory);
   std::vector<double> g(n), xn(n), gn(n), d(n), pg(n), q(n);
@@ -184,6 +189,26 @@ inline LbfgsResult lbfgsb_minimize(const Objective& fun, double* x, const double
     }
   }
   burn(x);
+  return res;
+}
+
+// The same run driven through the resumable state machine (lbfgs_step.hpp) -- the implementation the device runs too.
+inline LbfgsResult lbfgsb_minimize(const Objective& fun, double* x, const double* lo, const double* hi, int n, const LbfgsOptions& opt) {
+  LbfgsResult res;
+  if (n > LBFGS_MAXN) return lbfgsb_minimize_loops(fun, x, lo, hi, n, opt);  // (never the GP: it has at most 66 parameters)
+  std::vector<double> g(n);
+  LbfgsState st;
+  lbfgs_begin(st, x, lo, hi, n, opt.maxeval, opt.memory, opt.pgtol, opt.ftol, opt.fixed_work);
+  for (int i = 0; i < n; ++i) x[i] = st.x[i];  // clipped start point (also the result if nothing is ever accepted)
+  for (;;) {
+    const double f = fun(lbfgs_request(st), g.data());
+    if (!lbfgs_advance(st, f, g.data())) break;
+  }
+  for (int i = 0; i < n; ++i) x[i] = st.x[i];
+  res.f = st.f;
+  res.nevals = st.nevals;
+  res.iterations = st.iterations;
+  res.converged = st.converged != 0;
   return res;
 }
 

@@ -353,3 +353,52 @@ def test_nan_features_stay_nan(n, dtype):
         ok = np.arange(m) != 3
         assert np.all(np.isfinite(mean[ok])) and np.all(np.isfinite(var[ok]))
     fk.release()
+
+
+@pytest.mark.parametrize("n,d,nu,dtype", [(128, 8, 2.5, np.float64), (100, 2, 1.5, np.float64), (64, 32, 0.5, np.float64), (17, 3, math.inf, np.float64),
+                                           (1, 1, 2.5, np.float64), (128, 5, 2.5, np.float32), (77, 16, 1.5, np.float32)])
+def test_single_launch_path_for_the_reference_regime(n, d, nu, dtype, monkeypatch):
+    # Up to 128 rows (the reference's own regime, minimize.rs:118-120) one evaluation is ONE launch that keeps K, L, L^-1, K^-1 and
+    # alpha in the LDS (small_eval_kernel).  It must agree with the general five-launch path (HBEGP_SMALL=0) far inside the bar
+    # -- same kernel matrix and factor, other summation orders behind them -- and with the oracle at the bar; fit, extend and
+    # predict run on top of it.
+    rng = np.random.default_rng(1000 * n + d)
+    X = rng.random((n, d)).astype(dtype)
+    y = (np.sin(3.0 * X[:, 0].astype(np.float64)) + 0.3 * rng.standard_normal(n) + 1.0).astype(dtype)
+    ell = 0.4 + 0.6 * rng.random(d) * math.sqrt(d)
+    c = 0.5 + rng.random()
+    s2 = c * (0.05 + 0.2 * rng.random())
+    theta = np.concatenate([[math.log(s2), math.log(c)], np.log(ell)])
+    tol = 1e-8 if dtype == np.float64 else 1e-4
+
+    def run():
+        prob = gpr.Problem(X, y, nu=nu)
+        lml, grad = prob.lml_with_gradient(theta)
+        alpha, kinv, ldiag = prob.results()
+        prob.close()
+        fk = gpr.FittedKernel.extend(X, y, theta, nu=nu)
+        Xs = rng.random((5, d)).astype(dtype)
+        mean, var, _ = fk.predict(Xs)
+        a2, k2 = fk.arrays()
+        fk.release()
+        return dict(lml=lml, grad=grad, alpha=alpha, kinv=kinv, ldiag=ldiag, mean=mean, var=var, Xs=Xs, a2=a2, k2=k2)
+
+    rng_state = rng.bit_generator.state
+    small = run()
+    rng.bit_generator.state = rng_state
+    monkeypatch.setenv("HBEGP_SMALL", "0")
+    general = run()
+    cmp_tol = 1e-12 if dtype == np.float64 else 2e-5
+    for key in ("lml", "grad", "alpha", "kinv", "ldiag", "mean", "var", "a2", "k2"):
+        a, b = np.asarray(small[key], dtype=np.float64), np.asarray(general[key], dtype=np.float64)
+        assert np.all(np.isfinite(a))
+        assert float(np.max(np.abs(a - b))) <= cmp_tol * max(1.0, float(np.max(np.abs(b)))), key
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    ref = O.lml_with_gradient(X64, y64, s2, c, ell, nu)
+    assert abs(small["lml"] - ref["lml"]) <= tol * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(small["grad"], ref["grad"], rtol=0, atol=tol * max(1.0, np.abs(ref["grad"]).max()))
+    np.testing.assert_allclose(small["alpha"], ref["alpha"], rtol=0, atol=tol * max(1.0, np.abs(ref["alpha"]).max()))
+    np.testing.assert_allclose(small["kinv"], ref["k_inv"], rtol=0, atol=tol * max(1.0, np.abs(ref["k_inv"]).max()))
+    rm, rv, _ = O.predict(small["Xs"].astype(np.float64), X64, ref["alpha"], ref["k_inv"], c, ell, nu)
+    np.testing.assert_allclose(small["mean"], rm, rtol=0, atol=tol * max(1.0, np.abs(rm).max()))
+    np.testing.assert_allclose(small["var"], rv, rtol=0, atol=tol * c * (10 if dtype == np.float32 else 1))

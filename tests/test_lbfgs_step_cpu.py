@@ -1,0 +1,16 @@
+"""CPU: the resumable L-BFGS (csrc/lbfgs_step.hpp -- the form the persistent fit kernel runs on the device, and the host path
+too) evaluates exactly the points of the loop form it was derived from (lbfgsb_minimize_loops), bit for bit: 14 objectives incl.
+bounds, failing evaluations, fixed work, tiny budgets, 66 dimensions (tests/cpp/test_lbfgs_step.cpp)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_resumable_lbfgs_replays_the_loop_form(tmp_path):
+    exe = str(tmp_path / "test_lbfgs_step")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "test_lbfgs_step.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "DIFFERENT" not in out.stdout and out.stdout.count("same") == 14
