@@ -196,16 +196,22 @@ def parity_in_run(gpr, ctx, w, theta, Xs, timed_model, O, ref):
         log("parity: one more oracle evaluation at the timed fit's captured theta")
         rt = O.lml_with_gradient(X, y, s2t, ct, ellt, 2.5)
         rmt, rvt, _ = O.predict(Xs, X, rt["alpha"], rt["k_inv"], ct, ellt, 2.5)
-        out["timed_model"] = {
+        # the fit ends where the optimiser drove it (typically small noise): both sides solve with K and are good to ~cond(K) eps,
+        # so the bar there is max(1e-8, 100 cond(K) eps) -- the rule of tests/test_gpu_fit.py's trace replay -- with cond(K)
+        # from the eigenvalues of the oracle's kernel matrix
+        ev = np.linalg.eigvalsh(rt["kernel_matrix"])
+        cond = float(ev[-1] / ev[0])
+        bar_t = max(PARITY_BAR, 100.0 * cond * float(np.finfo(np.float64).eps))
+        tm_dev = {
             "lml_rel": abs(timed_model["lml"] - rt["lml"]) / max(1.0, abs(rt["lml"])),
             "mean_abs": rel(timed_model["mean"], rmt),
             "var_abs": float(np.max(np.abs(timed_model["var"] - rvt)) / ct),
-            "at": "the theta captured by the last timed fit; its predictions at the m candidates are the timed ones",
         }
-    worst = max([v for k, v in out.items() if k.endswith(("_rel", "_abs"))] +
-                [v for k, v in out.get("timed_model", {}).items() if k.endswith(("_rel", "_abs"))])
+        out["timed_model"] = dict(tm_dev, cond_K=cond, bar=bar_t, ok=bool(max(tm_dev.values()) <= bar_t),
+                                  at="the theta captured by the last timed fit; its predictions at the m candidates are the timed ones")
+    worst = max(v for k, v in out.items() if k.endswith(("_rel", "_abs")))
     out["worst"] = worst
-    out["ok"] = bool(worst <= PARITY_BAR)
+    out["ok"] = bool(worst <= PARITY_BAR) and out.get("timed_model", {}).get("ok", True)
     return out
 
 
@@ -579,7 +585,7 @@ def main():
             parity_failed = not par.get("ok", False)
         print(json.dumps(out), flush=True)
         if parity_failed:
-            log(f"PARITY FAILED: worst deviation {out['parity_in_run'].get('worst')} above {PARITY_BAR}")
+            log(f"PARITY FAILED: {json.dumps(out['parity_in_run'])}")
             if dist is not None:
                 dist.destroy_process_group()
             ctx.close()

@@ -146,7 +146,8 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 
   // f32: fp64 totals per F32_CHUNK contraction elements, exactly as gemm_kernel does (same chunk boundaries: same bits)
   constexpr bool CHUNKED = sizeof(T) == 4;
-  static_assert(!CHUNKED || BK == F32_CHUNK, "one stage = one accumulation chunk");
+  static_assert(!CHUNKED || F32_CHUNK % BK == 0, "an accumulation chunk is a whole number of stages");
+  int kabs = kbeg;  // f32: absolute contraction index behind the stages computed so far
   double tot[CHUNKED ? TMA : 1][CHUNKED ? TMB : 1][4];
   if constexpr (CHUNKED) {
 #pragma unroll
@@ -210,7 +211,8 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
     __builtin_amdgcn_sched_group_barrier(0x100, TMA + TMB, 0);  // reads first: their latency hides under the MFMAs
     __builtin_amdgcn_sched_group_barrier(0x008, TMA * TMB, 0);
     __builtin_amdgcn_sched_barrier(0);
-    flush();
+    kabs += BK;
+    if (CHUNKED && kabs % F32_CHUNK == 0) flush();
   };
   if (nstages > 0) {
     load_stage(ra0, rb0);
@@ -275,6 +277,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
     fetch();
   }
 
+  flush();  // f32: what the last (partial) chunk holds
   // epilogue: write-through stores (read by other workgroups of this launch)
   const int er0 = row0 + wm * (TA / G::WM), ec0 = col0 + wn * (TB / G::WN) + (lane & 15);
   const bool neg = (flags & DAGF_NEG) != 0;

@@ -74,7 +74,10 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 // =================================================================================================================
 // Tile GEMM
 // =================================================================================================================
-constexpr int F32_CHUNK = 32;  // contraction elements per f32 accumulation chunk (see gemm_kernel)
+#ifndef HBEGP_F32_CHUNK
+#define HBEGP_F32_CHUNK 32  /* round 4, 64 (make variant DEFS=-DHBEGP_F32_CHUNK=64): C5 f32 fits 8.63 -> 9.70 /s, M f32 2.78 -> 2.79, but alpha at cond(K) = 7e4 leaves the plain 1e-4 bar (8e-5 -> 1.03e-4, tests/test_gpu_fullsize.py): stays 32 */
+#endif
+constexpr int F32_CHUNK = HBEGP_F32_CHUNK;  // contraction elements per f32 accumulation chunk (see gemm_kernel); boundaries at absolute multiples
 
 template <typename T, int TILE, int KM = 0>
 struct GemmGeom {
@@ -256,6 +259,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
         }
     }
   };
+  int kabs = kbeg;  // f32: absolute contraction index of the stage being computed (chunk boundaries are absolute multiples of F32_CHUNK)
 
   // fragment addressing: element (outer index o, contraction k) at o*so + k*sk
   const int soA = akm ? 1 : SK, skA = akm ? SM : 1;
@@ -291,8 +295,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       if (k4 == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);
       if (k4 + 1 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
-      if (CHUNKED && ((k4 + 1) * 4) % F32_CHUNK == 0) flush();
+      if (CHUNKED && (kabs + (k4 + 1) * 4) % F32_CHUNK == 0) flush();
     }
+    kabs += BK;
   };
 
   if constexpr (TILE == 128 && !HBEGP_T128_TWOSETS) {
@@ -356,8 +361,9 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);  // reads first: their latency hides under the MFMAs
       __builtin_amdgcn_sched_group_barrier(0x008, TM * TM, 0);
       __builtin_amdgcn_sched_barrier(0);
-      static_assert(!CHUNKED || BK == F32_CHUNK, "f32 64-tile: one stage = one accumulation chunk");
-      flush();
+      static_assert(!CHUNKED || F32_CHUNK % BK == 0, "f32 64-tile: an accumulation chunk is a whole number of stages");
+      kabs += BK;
+      if (CHUNKED && kabs % F32_CHUNK == 0) flush();
     };
     if (nstages > 0) {
       load_stage(ra0, rb0);
@@ -429,6 +435,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmLaunch g) {
   }
 
   // epilogue
+  flush();  // f32: what the last (partial) chunk holds
   if (bad != 0) return;
   T* Cg = static_cast<T*>(op.C);
   const int row0 = ti * TILE + wm * (TILE / 2), col0 = tj * TILE + wn * (TILE / 2) + (lane & 15);
