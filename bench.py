@@ -290,10 +290,13 @@ def roofline_block(gpr, ctx, X, y, theta, nslots, ms_per_step, n_evals, extra_fl
     traffic, traffic_note = None, None
     if pmc_ok and is_dag:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_3slot.json")))["kernels"]
+            src = "r04_pmc_3slot.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_3slot.json")) else "r03_pmc_3slot.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", src)))
+            pmc = pmc.get("kernels", pmc)
             key = [k for k in pmc if "dag_kernel" in k]
-            traffic = pmc[key[0]]["fetch_bytes_per_launch"] + pmc[key[0]]["write_bytes_per_launch"]
-            traffic_note = ("FETCH_SIZE x2 + WRITE_SIZE per launch from profiles/r03_pmc_3slot.json: ONE 96-workgroup launch running alone -- "
+            rec = pmc[key[0]]
+            traffic = (rec.get("fetch_bytes_per_launch") or rec["fetch_bytes_per_dispatch"]) + (rec.get("write_bytes_per_launch") or rec["write_bytes_per_dispatch"])
+            traffic_note = (f"FETCH_SIZE x2 + WRITE_SIZE per launch from profiles/{src}: ONE 96-workgroup launch running alone -- "
                             "rocprofv3 --pmc serialises dispatches, so counters of three co-resident launches cannot be collected; "
                             "algorithmic (compulsory) bytes per launch: K lower in, L / L^-1 / K^-1 lower out = 4 x n^2/2 x 8 B")
         except Exception:
