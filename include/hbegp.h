@@ -25,6 +25,19 @@
  *   - Return value: one of HBEGP_* below.  Negative = usage/runtime error (see hbegp_last_error()).
  *   - All compute runs in hand-written HIP kernels on gfx950; there is no CPU fallback.  Without a GPU
  *     hbegp_ctx_create() fails with HBEGP_ENODEV.
+ *   - Accuracy against the reference's CPU arithmetic (ndarray + LAPACK potrf/potrs/potri), relative to max(1, scale), the
+ *     predictive variance relative to the amplitude: f64 1e-8 on lml, gradient, alpha, K^-1, mean and variance, or
+ *     100 cond(K) eps where cond(K) puts LAPACK's own digits beyond that (corners of the box an optimiser visits).
+ *     f32 (`--use-32`) 1e-4 on lml, gradient, mean and variance; alpha and K^-1 meet 1e-4 up to cond(K) ~ 7e4 on the paths a
+ *     caller gets by default (the task queue's right-looking order: n >= 1024 inside a fit, n >= 2048 outside; the single
+ *     launch up to n = 128), and max(1e-4, 2 x the deviation of LAPACK's own f32 path) otherwise -- between n = 129 and those
+ *     thresholds f32 panel solves go through the explicit inverse of the whole left half, which costs K^-1 ~20 % more
+ *     deviation at cond(K) = 7e4 (1.2e-4; LAPACK f32: 1.7e-4).  tests/test_gpu_fullsize.py holds both statements.
+ *   - Problems of at most 128 rows and 32 features (the reference's own regime, src/core/minimize.rs:118-120) take a path of
+ *     their own: one evaluation is one launch that keeps K, L, L^-1, K^-1 and alpha in a compute unit's LDS, and one optimiser
+ *     run of a fit is one persistent launch (evaluation + bounded L-BFGS step + capture on the device); the host only starts
+ *     the runs side by side and collects.  Same entry points, same contracts; HBEGP_SMALL=0 / HBEGP_SMALL_FIT=0 select the
+ *     general path / the host-driven optimiser for comparison.
  */
 #ifndef HBEGP_H
 #define HBEGP_H
@@ -120,7 +133,7 @@ typedef struct hbegp_fit_options {
   /* optional trace of the evaluations, for replay parity against the oracle: trace_theta[trace_cap*p],
    * trace_lml[trace_cap] (-inf when not PD), trace_grad[trace_cap*p], trace_run[trace_cap].  Concurrent runs record as
    * their evaluations complete (the first trace_cap of them are kept); on return the records are sorted by run, and
-   * within a run they are in evaluation order.  Sorting needs trace_run; without it the order is completion order. */
+   * within a run they are in evaluation order (problems of at most 128 rows: the first trace_cap records in that order).  Sorting needs trace_run; without it the order is completion order. */
   double* trace_theta;
   double* trace_lml;
   double* trace_grad;

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from hbetune_rs_amd import gpr, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 w = synth.make_workload("M", n=n)

@@ -28,11 +28,12 @@ echo "[6] PMC traffic of the task-queue launch, three slots (rocprofv3 --pmc ser
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p_fetch -o run -- python3 $ROOT/tools/profile_3slot.py 6 > $OUT/p_fetch.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/p_write -o run -- python3 $ROOT/tools/profile_3slot.py 6 > $OUT/p_write.log 2>&1 && \
-python3 $ROOT/tools/pmc_summarize.py $OUT/p_fetch/run_counter_collection.csv $OUT/p_write/run_counter_collection.csv $OUT/r04_pmc_3slot.json > $OUT/pmc3.log 2>&1
+python3 $ROOT/tools/pmc_summarize.py $OUT/p_fetch/run_counter_collection.csv $OUT/p_write/run_counter_collection.csv $OUT/r04_pmc_3slot.json "python3 tools/profile_3slot.py 6 (three slots evaluating at once; --pmc serialises the dispatches)" > $OUT/pmc3.log 2>&1
 find $OUT -name "*.db" -delete 2>/dev/null; rm -rf $OUT/p_fetch $OUT/p_write
 cd $ROOT
 echo "[7] kernel trace of a small fit (persistent fit kernel)" | tee -a $OUT/progress.txt
 cd /tmp
+export PYTHONPATH=$ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smallfit -o run -- python3 $ROOT/tools/fit_timing_probe.py 128 > $OUT/smallfit.log 2>&1
 cp $OUT/smallfit/run_kernel_stats.csv $OUT/r04_small_fit_kernel_stats.csv 2>/dev/null; rm -rf $OUT/smallfit
 cd $ROOT
