@@ -17,6 +17,7 @@ struct EvalParams {
   double noise;      // sigma^2
   double amp;        // c
   double ell[MAXD];  // length scales
+  unsigned long long seq;  // serial number of the evaluation (host); the last kernel echoes it into EvalOut::seq of the pinned result block
 };
 
 // Per-evaluation scalar results (device -> pinned host).
@@ -29,6 +30,19 @@ struct EvalOut {
   int n_warn;      // predict: variances below -sqrt(1e-5)
   int done;        // bit 0: lml written by this evaluation, bit 1: gradient written (a kernel that never ran leaves them clear)
   int pad_;
+  unsigned long long seq;  // pinned copy only: EvalParams::seq of the evaluation these results belong to, stored LAST (system scope)
+};
+
+// What the first kernel of an evaluation (the kernel-matrix assembly) does besides its tiles when the evaluation is driven
+// through pinned host memory (hbegp.cpp, HBEGP_HOSTIO): its workgroup 0 copies the parameters it reads from the host block to
+// device memory for the later kernels, poisons the result block and clears the task queue's control words -- one graph node in
+// front of the long kernel instead of four (parameter copy, reset kernel, assembly, memset), each of which the GPU spent
+// ~30-50 us waiting for while three host threads were enqueuing their graphs.
+struct EvalPrologue {
+  EvalParams* dP = nullptr;   // device copy of the parameters (null: not the first kernel -- `info` is honoured as usual)
+  EvalOut* out = nullptr;     // device result block to poison
+  int* ctrl = nullptr;        // task-queue control words to clear (may be null)
+  int ctrl_words = 0;
 };
 
 // One tile-GEMM operation on row-major matrices, in units of TILE x TILE tiles (global tile coordinates).
@@ -154,7 +168,8 @@ template <typename T>
 void launch_gemm(const GemmLaunch& g, int tile, hipStream_t s);  // tile in {32, 64, 128}
 
 template <typename T>
-void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s);
+void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s,
+                 const EvalPrologue* pro = nullptr);
 
 // Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag;
 // W3 (optional): the lower triangle of L_blk itself.
@@ -243,6 +258,10 @@ void launch_set_info(int* info, int value, hipStream_t s);
 // start of an evaluation: info = n_warn = done = 0, lml and gradient poisoned with NaN (a launch that was rejected or
 // skipped can then never pass for a result)
 void launch_reset_out(EvalOut* out, hipStream_t s);
+// Last kernel of an evaluation driven through pinned host memory: copies the device result block to the pinned one and then,
+// behind a system-scope fence, stores P->seq into hout->seq -- the host thread spins on that word instead of sleeping in
+// hipStreamSynchronize (interrupt wake-up: ~50 us of every evaluation).
+void launch_publish_out(const EvalOut* out, EvalOut* hout, const EvalParams* P, hipStream_t s);
 // throws nothing: returns the first pending launch error of the calling thread's device (hipGetLastError)
 void init_kernels();
 

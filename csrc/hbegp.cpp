@@ -166,7 +166,7 @@ struct HostPool {
       }
     }
     void* p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocCoherent);  // fine-grained: a host thread spins on words the GPU writes (Problem::wait_eval)
     if (e != hipSuccess) throw HipError{e, "hipHostMalloc (pool)", __LINE__};
     return p;
   }
@@ -390,6 +390,9 @@ struct Slot {
   int dag_target = 0;   // alpha buffer the task-queue launch writes (its alpha / lml tasks)
   T* dag_kinv = nullptr;  // K^-1 buffer the task-queue launch writes (its X^T X tiles); null: factorisation only
   int gemm_ord = 0;     // ordinal of the next GEMM launch inside the current evaluation (indexes the static schedules)
+  unsigned long long seq = 0;  // serial number of the last evaluation handed to the device (EvalParams::seq)
+  bool ctrl_cleared = false;   // the evaluation's first kernel clears dag_ctrl itself (EvalPrologue): no memset node
+  bool published = false;      // the evaluation ends with publish_out_kernel: the host may spin on hOut->seq
 };
 
 struct ProblemBase {
@@ -440,6 +443,13 @@ struct Problem : ProblemBase {
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
   bool small_ = false;                      // np = 128, d <= 32: one evaluation = ONE launch (small_eval_kernel), everything in the LDS
   bool like_fit_ = false;                   // path selection of a fit (task queue from 8 blocks on) although there is one slot
+  // HBEGP_HOSTIO (default 1): an evaluation is driven through the slot's pinned blocks -- the first kernel reads the parameters
+  // there and prepares the device-side blocks (EvalPrologue), the last one copies the results back and publishes the
+  // evaluation's serial number, which the host thread spins on.  0: parameter copy + reset kernel + memset in front, a result
+  // copy behind, hipStreamSynchronize (round 1-3).  Measured on config M (three optimiser runs, rocprofv3 kernel trace): the GPU
+  // waited 52 + 54 + 29 us per evaluation for the host to enqueue the three extra nodes in front of the long kernel, and 84 us
+  // between two evaluations.
+  bool hostio_ = true;
   int leaf_dbg_ = 0;                        // HBEGP_LEAF_DBG: debug bits of the diagonal-block kernel (16: helper waves start late)
 
   // single_shot: the problem runs one evaluation (extend): skip the static schedule tables, every GEMM launch is ad hoc
@@ -469,6 +479,7 @@ struct Problem : ProblemBase {
     // cost more in launch gaps and HBM round trips than in arithmetic; one workgroup does the whole evaluation in its LDS
     // instead (HBEGP_SMALL=0: the general path, which the tests compare it with).
     small_ = np == NB && d <= SMALL_EVAL_MAXD && !refine_ && env_int("HBEGP_SMALL", 1) != 0;
+    hostio_ = env_int("HBEGP_HOSTIO", 1) != 0;
     const size_t nn = (size_t)np * np;
     Xd.assign(c->devs.size(), nullptr);
     yd.assign(c->devs.size(), nullptr);
@@ -868,7 +879,8 @@ struct Problem : ProblemBase {
     if (dag_ && !adhoc_) {
       // the whole recursion in ONE persistent launch: workgroups pull diagonal-block and tile tasks from an ordered queue
       if (dry_) return;
-      HIPCHECK(hipMemsetAsync(s.dag_ctrl, 0, dag_ctrl_bytes, s.stream));
+      if (!s.ctrl_cleared) HIPCHECK(hipMemsetAsync(s.dag_ctrl, 0, dag_ctrl_bytes, s.stream));
+      s.ctrl_cleared = false;
       DagLaunch g{};
       const DagVariant& var = dag_var[s.dag_variant];
       g.tasks = var.tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
@@ -979,13 +991,26 @@ struct Problem : ProblemBase {
       CHECK_LAUNCHES();
       return;
     }
+    const bool hostio = hostio_ && !in_queue;
     if (!dry_) {
-      HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
-      launch_reset_out(s.dOut, s.stream);
-      if (!in_queue) {
+      if (hostio) {
+        EvalPrologue pro;
+        pro.dP = s.dP; pro.out = s.dOut;
+        if (dag_ && !adhoc_) {
+          pro.ctrl = s.dag_ctrl; pro.ctrl_words = (int)(dag_ctrl_bytes / sizeof(int));
+          s.ctrl_cleared = true;
+        }
         if (tm) tm->begin(PhaseTimer::KMAT);
-        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.hP, s.W1, info, s.stream, &pro);
         if (tm) tm->end();
+      } else {
+        HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
+        launch_reset_out(s.dOut, s.stream);
+        if (!in_queue) {
+          if (tm) tm->begin(PhaseTimer::KMAT);
+          launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+          if (tm) tm->end();
+        }
       }
     }
     s.dag_target = target;
@@ -1014,8 +1039,35 @@ struct Problem : ProblemBase {
       launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream);
       if (tm) tm->end();
     }
+    if (hostio) {
+      launch_publish_out(s.dOut, s.hOut, s.dP, s.stream);
+      s.published = true;
+    }
     CHECK_LAUNCHES();
-    HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+    if (!hostio) {
+      HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
+      s.published = false;
+    }
+  }
+
+  // The host side of the end of an evaluation.  Published evaluations (HBEGP_HOSTIO): spin on the serial number the last kernel
+  // stores into the pinned result block behind a system-scope fence; hipStreamSynchronize sleeps on an interrupt and wakes up
+  // ~50 us late, which three optimiser runs pay 150 times each.  A kernel that faults never publishes: after two seconds the
+  // thread falls back to hipStreamSynchronize, which reports the fault (or simply waits for a very long evaluation).
+  void wait_eval(Slot<T>& s) {
+    if (s.published) {
+      const volatile unsigned long long* q = &s.hOut->seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned it = 1;; ++it) {
+        if (*q == s.seq) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          return;
+        }
+        __builtin_ia32_pause();
+        if ((it & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+      }
+    }
+    HIPCHECK(hipStreamSynchronize(s.stream));
   }
 
   // Kernel matrix + Cholesky/inverse-factor recursion only (no alpha, no K^-1): leaves X = L^-1 in the slot's W2.
@@ -1137,6 +1189,7 @@ struct Problem : ProblemBase {
     HIPCHECK(hipSetDevice(s.dev));
     static const bool graphs_on = env_int("HBEGP_NO_GRAPH", 0) == 0;
     s.dag_variant = variant_now(di);
+    s.hP->seq = ++s.seq;
     if (use_graph && graphs_on) {
       hipGraphExec_t& ge = s.graph[s.dag_variant][target][want_grad ? 1 : 0];
       if (!ge) {
@@ -1156,7 +1209,8 @@ struct Problem : ProblemBase {
     } else {
       enqueue_eval(s, di, target, want_grad, nullptr);
     }
-    HIPCHECK(hipStreamSynchronize(s.stream));
+    s.published = hostio_ && !small_ && !(dag_ && dag_full_ && !adhoc_);  // what enqueue_eval records when it is not replayed from a graph
+    wait_eval(s);
     s.last_target = target;
     const int p = d + 2;
     if (s.hOut->info < 0) {

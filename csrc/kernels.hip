@@ -1068,13 +1068,38 @@ __device__ __forceinline__ T kmat_entry(T dist2, int nu2, T amp, T noise, bool d
   return diag ? v + noise : v;
 }
 
+// the poison pattern run_eval looks for in outputs that were never written (a payload no arithmetic produces)
+__device__ __forceinline__ void poison_out(EvalOut* out, int t) {
+  const double nan = __longlong_as_double(0x7ff8000000005eedLL);
+  if (t == 0) {
+    out->lml = nan; out->yalpha = nan; out->logdet = nan;
+    out->info = 0; out->n_warn = 0; out->done = 0;
+  }
+  if (t < MAXP) out->grad[t] = nan;
+}
+// One workgroup of 256 threads: parameters host -> device, poisoned result block, cleared task-queue control words.
+__device__ __forceinline__ void eval_prologue(const EvalParams* __restrict__ P, const EvalPrologue& pro) {
+  const int t = threadIdx.x;
+  constexpr int PW = (int)(sizeof(EvalParams) / 8);
+  static_assert(sizeof(EvalParams) % 8 == 0 && PW <= 256, "EvalParams is copied as 8-byte words by one workgroup");
+  if (t < PW) reinterpret_cast<unsigned long long*>(pro.dP)[t] = reinterpret_cast<const unsigned long long*>(P)[t];
+  poison_out(pro.out, t);
+  for (int i = t; i < pro.ctrl_words; i += 256) pro.ctrl[i] = 0;
+}
+
 // 64x64 tile per workgroup; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.  NU2: the Matern order at
 // compile time (no branch per entry); tiles that lie wholly inside the n x n matrix skip the per-entry bounds tests.
 template <typename T, int NU2>
 __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int n, int d, int np,
                                                    const EvalParams* __restrict__ P, T* __restrict__ W,
-                                                   const int* info) {
-  if (*info != 0) return;
+                                                   const int* info, EvalPrologue pro) {
+  if (pro.dP) {
+    // first kernel of an evaluation (engine.hpp, EvalPrologue): nothing has failed yet, `info` still holds the previous
+    // evaluation's value and is not read; workgroup 0 prepares the device-side blocks for the kernels behind this one
+    if (blockIdx.x == 0) eval_prologue(P, pro);
+  } else if (*info != 0) {
+    return;
+  }
   extern __shared__ __align__(16) char smem_raw[];
   T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] scaled rows of the i tile (feature-major)
   T* xj = xi + (size_t)d * 64;             // [d][64]
@@ -1138,19 +1163,21 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
 }
 
 template <typename T>
-void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s) {
+void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s,
+                 const EvalPrologue* pro) {
   const int nt = np / 64;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
   const dim3 grid(nt * (nt + 1) / 2), block(256);
+  const EvalPrologue pr = pro ? *pro : EvalPrologue{};
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info); break;
-    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info); break;
-    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info); break;
-    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info); break;
+    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
   }
 }
-template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t);
-template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t);
+template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t, const EvalPrologue*);
+template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t, const EvalPrologue*);
 
 // =================================================================================================================
 // alpha = K^-1 y through the explicit inverse factor: w = X y, alpha = X^T w;  lml pieces (lml.rs:54-59)
@@ -2513,16 +2540,22 @@ void init_kernels() {
 __global__ void set_info_kernel(int* info, int value) { *info = value; }
 void launch_set_info(int* info, int value, hipStream_t s) { hipLaunchKernelGGL(set_info_kernel, dim3(1), dim3(1), 0, s, info, value); }
 
-__global__ void reset_out_kernel(EvalOut* out) {
-  const int t = threadIdx.x;
-  const double nan = __longlong_as_double(0x7ff8000000005eedLL);  // the poison pattern run_eval looks for (a payload no arithmetic produces)
-  if (t == 0) {
-    out->lml = nan; out->yalpha = nan; out->logdet = nan;
-    out->info = 0; out->n_warn = 0; out->done = 0;
-  }
-  if (t < MAXP) out->grad[t] = nan;
-}
+__global__ void reset_out_kernel(EvalOut* out) { poison_out(out, threadIdx.x); }
 void launch_reset_out(EvalOut* out, hipStream_t s) { hipLaunchKernelGGL(reset_out_kernel, dim3(1), dim3(128), 0, s, out); }
+
+// device result block -> pinned host block, then the evaluation's serial number behind a system-scope fence (engine.hpp)
+__global__ void __launch_bounds__(128) publish_out_kernel(const EvalOut* __restrict__ out, EvalOut* hout, const EvalParams* __restrict__ P) {
+  const int t = threadIdx.x;
+  constexpr int OW = (int)(offsetof(EvalOut, seq) / 8);
+  static_assert(offsetof(EvalOut, seq) % 8 == 0 && OW <= 128, "EvalOut is copied as 8-byte words by one workgroup");
+  if (t < OW) reinterpret_cast<unsigned long long*>(hout)[t] = reinterpret_cast<const unsigned long long*>(out)[t];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&hout->seq, P->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish_out(const EvalOut* out, EvalOut* hout, const EvalParams* P, hipStream_t s) {
+  hipLaunchKernelGGL(publish_out_kernel, dim3(1), dim3(128), 0, s, out, hout, P);
+}
 
 #include "dag_kernel.inc.hpp"
 
