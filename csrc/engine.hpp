@@ -178,13 +178,16 @@ void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t
 
 // alpha = X^T (X y), lml pieces.  X lower-triangular np x np in W2.  part: [np/256][np] scratch.
 template <typename T>
+// ticket (device int, zero between launches): the last workgroup of the reduction forms the lml itself (no lml_final launch).
 void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, T* wbuf, double* part, T* alpha,
-                      EvalOut* out, const int* info, hipStream_t s);
+                      EvalOut* out, const int* info, hipStream_t s, int* ticket = nullptr);
 
 // lml gradient: g_j = 1/2 sum_ik (alpha alpha^T - Kinv)_ik dK_ik/dtheta_j without materialising dK.
 template <typename T>
+// ticket (device int, zero between launches): the launch's last workgroup finalises the gradient itself and, with hout, copies
+// the result block to the pinned one and publishes the evaluation's serial number -- no finalize / publish launches behind it
 void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
-                      double* part, EvalOut* out, const int* info, hipStream_t s);
+                      double* part, EvalOut* out, const int* info, hipStream_t s, int* ticket = nullptr, EvalOut* hout = nullptr);
 size_t gradtrace_part_elems(int np, int d);
 
 template <typename T>

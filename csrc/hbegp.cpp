@@ -371,6 +371,7 @@ struct Slot {
   double *part_t = nullptr, *part_g = nullptr;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
+  int* tickets = nullptr;    // [0] alpha / lml reduction, [1] gradient: "last workgroup finishes the launch's job" counters (zero between launches)
   unsigned long long* dag_trace = nullptr;  // HBEGP_DAG_TRACE: per-task time stamps of the last evaluation
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
@@ -517,7 +518,7 @@ struct Problem : ProblemBase {
           const size_t b_part_t = up(sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64));
           const size_t b_part_g = up(sizeof(double) * gradtrace_part_elems(np, d));
           const size_t b_p = up(sizeof(EvalParams)), b_o = up(sizeof(EvalOut));
-          s.small_slab_bytes = 4 * b_vec + b_part_t + b_part_g + b_p + b_o;
+          s.small_slab_bytes = 4 * b_vec + b_part_t + b_part_g + b_p + b_o + 256;
           bool fs = false;
           s.small_slab = g_pool.get(s.dev, s.small_slab_bytes, &fs);
           char* q = static_cast<char*>(s.small_slab);
@@ -528,8 +529,10 @@ struct Problem : ProblemBase {
           s.part_t = reinterpret_cast<double*>(q); q += b_part_t;
           s.part_g = reinterpret_cast<double*>(q); q += b_part_g;
           s.dP = reinterpret_cast<EvalParams*>(q); q += b_p;
-          s.dOut = reinterpret_cast<EvalOut*>(q);
+          s.dOut = reinterpret_cast<EvalOut*>(q); q += b_o;
+          s.tickets = reinterpret_cast<int*>(q);
           HIPCHECK(hipMemsetAsync(s.dOut, 0, sizeof(EvalOut), nullptr));
+          HIPCHECK(hipMemsetAsync(s.tickets, 0, 256, nullptr));
           const size_t h_p = up(sizeof(EvalParams));
           s.host_slab_bytes = h_p + up(sizeof(EvalOut));
           s.host_slab = g_host_pool.get(s.host_slab_bytes);
@@ -1018,7 +1021,7 @@ struct Problem : ProblemBase {
     chol_inv(s, di, nb, tm);
     if (!dry_ && !in_queue) {
       if (tm) tm->begin(PhaseTimer::ALPHA);
-      launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream);
+      launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream, hostio ? s.tickets : nullptr);
       if (tm) tm->end();
     }
     if (!(dag_ && dag_lauum_ && !adhoc_)) {
@@ -1036,11 +1039,13 @@ struct Problem : ProblemBase {
     if (dry_) return;
     if (want_grad) {
       if (tm) tm->begin(PhaseTimer::GRAD);
-      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream);
+      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation
+      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream,
+                          hostio ? s.tickets + 1 : nullptr, hostio ? s.hOut : nullptr);
       if (tm) tm->end();
     }
     if (hostio) {
-      launch_publish_out(s.dOut, s.hOut, s.dP, s.stream);
+      if (!want_grad) launch_publish_out(s.dOut, s.hOut, s.dP, s.stream);
       s.published = true;
     }
     CHECK_LAUNCHES();

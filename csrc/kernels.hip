@@ -1197,6 +1197,29 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// What the LAST workgroup of a launch to finish does for the whole launch (the ticket pattern).  The L2s of the eight XCDs
+// are not coherent with each other, and an agent-scope release fence writes back the whole L2 of the XCD (measured on config M:
+// one per workgroup of the gradient launch doubled that launch, 138 -> 290 us, and slowed the other slots' task-queue
+// launches by 10 %: it evicts their working set too).  So, as in the task-queue kernel: the few words a workgroup hands over
+// (thread 0 writes them) are stored write-through (publish_f64), thread 0 drains them (s_waitcnt vmcnt(0)) and takes a ticket
+// with a relaxed agent-scope atomic; the workgroup that draws the last ticket runs ONE agent-scope acquire (drops its CU's L1
+// and the stale lines of its L2) and then sees everybody's words.  The ticket word is left at zero for the next launch.
+// Returns true (uniformly) in the last workgroup.
+__device__ __forceinline__ void publish_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_workgroup(int* ticket) {
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = tk == (int)gridDim.x * (int)gridDim.y - 1;
+    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return last;
+}
+
 // one wave per row: w_i = sum_{k<=i} X[i][k] y[k]
 template <typename T>
 __global__ void __launch_bounds__(256) trmv_n_kernel(const T* __restrict__ Xinv, int np, int n, const T* __restrict__ y,
@@ -1223,7 +1246,22 @@ __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv,
   double acc = 0;
   const int i_begin = chunk * 256, i_end = min(i_begin + 256, np);
   if (i_end > blockIdx.x * 64) {
-    for (int i = i_begin + sgrp; i < i_end; i += 4)
+    // the same chain of fused multiply-adds in the same order (i ascending in steps of four); the loads of eight steps are
+    // issued together -- as a plain loop the compiler waited for each load before the next (17 us at n=256: 64 round trips)
+    int i = i_begin + sgrp;
+    for (; i + 28 < i_end; i += 32) {
+      T xv[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int iu = i + 4 * u;
+        xv[u] = (iu >= j) ? Xinv[(size_t)iu * np + j] : T(0);
+        wv[u] = w[iu];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i + 4 * u >= j) acc = __builtin_fma((double)xv[u], (double)wv[u], acc);
+    }
+    for (; i < i_end; i += 4)
       if (i >= j) acc = __builtin_fma((double)Xinv[(size_t)i * np + j], (double)w[i], acc);
   }
   red[sgrp][c] = acc;
@@ -1231,11 +1269,25 @@ __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv,
   if (sgrp == 0) part[(size_t)chunk * np + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// lml = -1/2 y^T alpha - sum log L_ii - n/2 log(2 pi)   (lml.rs:57-59); fixed summation order; one thread
+__device__ __forceinline__ void lml_final(const double* __restrict__ sums, int nblocks, int n, EvalOut* out) {
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    s1 += sums[2 * b];
+    s2 += sums[2 * b + 1];
+  }
+  out->yalpha = s1;
+  out->logdet = s2;
+  out->lml = __builtin_fma(-0.5, s1, -s2) - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
+  atomicOr(&out->done, 1);
+}
+
 // alpha_j = sum_chunks part[c][j]; per-workgroup partial sums of y^T alpha and sum log L_jj  (256 columns per workgroup)
 template <typename T>
 __global__ void __launch_bounds__(256) alpha_reduce_kernel(const double* __restrict__ part, int nchunks, int np, int n,
                                                            const T* __restrict__ y, const T* __restrict__ ldiag,
-                                                           T* __restrict__ alpha, double* __restrict__ sums, const int* info) {
+                                                           T* __restrict__ alpha, double* __restrict__ sums, const int* info,
+                                                           EvalOut* out_final, int* ticket) {
   if (*info != 0) return;
   __shared__ double red[4];
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -1253,43 +1305,36 @@ __global__ void __launch_bounds__(256) alpha_reduce_kernel(const double* __restr
   const double s1 = block_sum(ya, red);
   const double s2 = block_sum(ld, red);
   if (threadIdx.x == 0) {
-    sums[2 * blockIdx.x] = s1;
-    sums[2 * blockIdx.x + 1] = s2;
+    publish_f64(&sums[2 * blockIdx.x], s1);
+    publish_f64(&sums[2 * blockIdx.x + 1], s2);
   }
+  // out_final: the last workgroup to finish forms the lml itself (one launch less on every evaluation's serial tail)
+  if (out_final && last_workgroup(ticket) && threadIdx.x == 0) lml_final(sums, (int)gridDim.x, n, out_final);
 }
 
 // lml = -1/2 y^T alpha - sum log L_ii - n/2 log(2 pi)   (lml.rs:57-59); fixed summation order
 __global__ void lml_final_kernel(const double* __restrict__ sums, int nblocks, int n, EvalOut* out, const int* info) {
   if (*info != 0) return;
-  if (threadIdx.x == 0) {
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblocks; ++b) {
-      s1 += sums[2 * b];
-      s2 += sums[2 * b + 1];
-    }
-    out->yalpha = s1;
-    out->logdet = s2;
-    out->lml = __builtin_fma(-0.5, s1, -s2) - (double)n / 2.0 * log(2.0 * 3.14159265358979323846);
-    atomicOr(&out->done, 1);
-  }
+  if (threadIdx.x == 0) lml_final(sums, nblocks, n, out);
 }
 
 template <typename T>
 void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, T* wbuf, double* part, T* alpha,
-                      EvalOut* out, const int* info, hipStream_t s) {
+                      EvalOut* out, const int* info, hipStream_t s, int* ticket) {
   hipLaunchKernelGGL((trmv_n_kernel<T>), dim3(np / 4), dim3(256), 0, s, Xinv, np, n, y, wbuf, info);
   const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
   hipLaunchKernelGGL((trmv_t_kernel<T>), dim3(np / 64, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info);
   // the per-workgroup sums live behind the chunk partials (part has room for nchunks*np + 2*np/256 doubles)
   double* sums = part + (size_t)nchunks * np;
   const int nblocks = (np + 255) / 256;
-  hipLaunchKernelGGL((alpha_reduce_kernel<T>), dim3(nblocks), dim3(256), 0, s, part, nchunks, np, n, y, ldiag, alpha, sums, info);
-  hipLaunchKernelGGL(lml_final_kernel, dim3(1), dim3(64), 0, s, sums, nblocks, n, out, info);
+  hipLaunchKernelGGL((alpha_reduce_kernel<T>), dim3(nblocks), dim3(256), 0, s, part, nchunks, np, n, y, ldiag, alpha, sums, info,
+                     ticket ? out : nullptr, ticket);
+  if (!ticket) hipLaunchKernelGGL(lml_final_kernel, dim3(1), dim3(64), 0, s, sums, nblocks, n, out, info);
 }
 template void launch_alpha_lml<double>(const double*, int, int, const double*, const double*, double*, double*, double*,
-                                       EvalOut*, const int*, hipStream_t);
+                                       EvalOut*, const int*, hipStream_t, int*);
 template void launch_alpha_lml<float>(const float*, int, int, const float*, const float*, float*, double*, float*,
-                                      EvalOut*, const int*, hipStream_t);
+                                      EvalOut*, const int*, hipStream_t, int*);
 
 // =================================================================================================================
 // Gradient of the lml: g_j = 1/2 sum_ik (alpha_i alpha_k - Kinv_ik) dK_ik/dtheta_j   (lml.rs:62-70)
@@ -1299,11 +1344,9 @@ template void launch_alpha_lml<float>(const float*, int, int, const float*, cons
 constexpr int GT_CHUNK = 8;  // length-scale parameters accumulated per register pass
 
 template <typename T, int NU2>
-__global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np,
-                                                        const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
-                                                        const T* __restrict__ alpha, double* __restrict__ part,
-                                                        const int* info) {
-  if (*info != 0) return;
+__device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, int d, int np,
+                                               const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
+                                               const T* __restrict__ alpha, double* __restrict__ part) {
   extern __shared__ __align__(16) char smem_raw[];
   T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] raw features of the i tile
   T* xj = xi + (size_t)d * 64;
@@ -1419,8 +1462,8 @@ __global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X,
     const double s0 = block_sum(g_noise, red);
     const double s1 = block_sum(g_amp, red);
     if (t == 0) {
-      my[0] = s0;
-      my[1] = s1;
+      publish_f64(&my[0], s0);
+      publish_f64(&my[1], s1);
     }
   }
   // pass B: length-scale gradients, GT_CHUNK parameters at a time
@@ -1454,10 +1497,68 @@ __global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X,
       const int k = kc + u;
       if (k < d) {  // uniform
         const double sres = block_sum(acc[u], red);
-        if (t == 0) my[2 + k] = sres;
+        if (t == 0) publish_f64(&my[2 + k], sres);
       }
     }
   }
+}
+
+// grad[j] = 0.5 * sum_blocks part[b][j] as finalize_grad_kernel forms it (thread t of 256 adds blocks t, t+256, ...; wave sums;
+// the four wave sums in order), computed by ONE wave per parameter: lane l carries the four threads l, l+64, l+128, l+192.
+__device__ __forceinline__ void finalize_grad_in_block(const double* __restrict__ part, int nblocks, int p, EvalOut* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = wave; j < p; j += 4) {
+    double acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      for (int b = q * 64 + lane; b < nblocks; b += 256) acc[q] += part[(size_t)b * p + j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0) publish_f64(&out->grad[j], 0.5 * (acc[0] + acc[1] + acc[2] + acc[3]));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have reached the L2 before the caller's barrier opens
+}
+
+// device result block -> pinned host block, then the evaluation's serial number behind a system-scope fence (engine.hpp).
+// Called by one whole workgroup (>= 128 threads) whose own writes to `out` are complete behind a barrier.
+__device__ __forceinline__ void publish_out_in_block(const EvalOut* out, EvalOut* hout, const EvalParams* __restrict__ P) {
+  const int t = threadIdx.x;
+  constexpr int OW = (int)(offsetof(EvalOut, seq) / 8);
+  static_assert(offsetof(EvalOut, seq) % 8 == 0 && OW <= 128, "EvalOut is copied as 8-byte words by one workgroup");
+  if (t < OW) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(out) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    reinterpret_cast<unsigned long long*>(hout)[t] = v;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&hout->seq, P->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// fin.out != null: the launch also finalises the gradient and publishes the evaluation (its last workgroup does), also when
+// the factorisation failed (info != 0: the tiles are skipped, the host still gets its answer).
+struct GradFinish {
+  EvalOut* out = nullptr;
+  EvalOut* hout = nullptr;   // pinned result block (null: finalise only)
+  int* ticket = nullptr;
+};
+template <typename T, int NU2>
+__global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np,
+                                                        const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
+                                                        const T* __restrict__ alpha, double* __restrict__ part,
+                                                        const int* info, GradFinish fin) {
+  const bool failed = *info != 0;
+  if (!fin.out) {
+    if (!failed) gradtrace_tile<T, NU2>(X, n, d, np, P, Kinv, alpha, part);
+    return;
+  }
+  if (!failed) gradtrace_tile<T, NU2>(X, n, d, np, P, Kinv, alpha, part);
+  if (!last_workgroup(fin.ticket)) return;
+  if (!failed) {
+    finalize_grad_in_block(part, (int)gridDim.x, d + 2, fin.out);
+    if (threadIdx.x == 0) atomicOr(&fin.out->done, 2);
+  }
+  __syncthreads();
+  if (fin.hout) publish_out_in_block(fin.out, fin.hout, P);
 }
 
 // grad[j] = 0.5 * sum_blocks part[b][j]  (fixed summation order -> bitwise reproducible)
@@ -1482,23 +1583,25 @@ size_t gradtrace_part_elems(int np, int d) {
 
 template <typename T>
 void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
-                      double* part, EvalOut* out, const int* info, hipStream_t s) {
+                      double* part, EvalOut* out, const int* info, hipStream_t s, int* ticket, EvalOut* hout) {
   const int nt = np / 64;
   const int nblocks = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
   const dim3 grid(nblocks), block(256);
+  GradFinish fin;
+  if (ticket) { fin.out = out; fin.hout = hout; fin.ticket = ticket; }
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
-    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
-    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
-    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info); break;
+    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
   }
-  hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, nblocks, d + 2, out, info);
+  if (!ticket) hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, nblocks, d + 2, out, info);
 }
 template void launch_gradtrace<double>(const double*, int, int, int, int, const EvalParams*, const double*, const double*,
-                                       double*, EvalOut*, const int*, hipStream_t);
+                                       double*, EvalOut*, const int*, hipStream_t, int*, EvalOut*);
 template void launch_gradtrace<float>(const float*, int, int, int, int, const EvalParams*, const float*, const float*,
-                                      double*, EvalOut*, const int*, hipStream_t);
+                                      double*, EvalOut*, const int*, hipStream_t, int*, EvalOut*);
 
 // =================================================================================================================
 // symmetrize: mirror the lower triangle into the upper one (what invc() hands back, lml.rs:62)
@@ -2544,14 +2647,8 @@ __global__ void reset_out_kernel(EvalOut* out) { poison_out(out, threadIdx.x); }
 void launch_reset_out(EvalOut* out, hipStream_t s) { hipLaunchKernelGGL(reset_out_kernel, dim3(1), dim3(128), 0, s, out); }
 
 // device result block -> pinned host block, then the evaluation's serial number behind a system-scope fence (engine.hpp)
-__global__ void __launch_bounds__(128) publish_out_kernel(const EvalOut* __restrict__ out, EvalOut* hout, const EvalParams* __restrict__ P) {
-  const int t = threadIdx.x;
-  constexpr int OW = (int)(offsetof(EvalOut, seq) / 8);
-  static_assert(offsetof(EvalOut, seq) % 8 == 0 && OW <= 128, "EvalOut is copied as 8-byte words by one workgroup");
-  if (t < OW) reinterpret_cast<unsigned long long*>(hout)[t] = reinterpret_cast<const unsigned long long*>(out)[t];
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) __hip_atomic_store(&hout->seq, P->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ void __launch_bounds__(128) publish_out_kernel(const EvalOut* out, EvalOut* hout, const EvalParams* __restrict__ P) {
+  publish_out_in_block(out, hout, P);
 }
 void launch_publish_out(const EvalOut* out, EvalOut* hout, const EvalParams* P, hipStream_t s) {
   hipLaunchKernelGGL(publish_out_kernel, dim3(1), dim3(128), 0, s, out, hout, P);

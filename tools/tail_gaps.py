@@ -20,7 +20,7 @@ for r in rows:
 dur = collections.defaultdict(list)
 gap = collections.defaultdict(list)
 for q, rs in byq.items():
-    if sum(1 for r in rs if r[2] == "dag_kernel") < 50:
+    if sum(1 for r in rs if r[2] == "kmat_kernel") < 50:
         continue
     for a, b in zip(rs, rs[1:]):
         dur[b[2]].append(b[1] - b[0])
@@ -32,7 +32,7 @@ for k, v in sorted(dur.items(), key=lambda kv: -np.sum(kv[1])):
 print()
 print(f"{'gap: previous -> next':50s} {'n':>6s} {'median us':>10s} {'mean us':>10s} {'p90 us':>10s} {'max us':>10s}")
 tot = 0.0
-nev = max(1, len(dur.get("dag_kernel", [])))
+nev = max(1, len(dur.get("kmat_kernel", [])))
 for k, v in sorted(gap.items(), key=lambda kv: -np.sum(kv[1])):
     v = np.array(v) / 1e3
     if len(v) < 20:
@@ -40,4 +40,6 @@ for k, v in sorted(gap.items(), key=lambda kv: -np.sum(kv[1])):
     tot += v.sum()
     print(f"{k[0] + ' -> ' + k[1]:50s} {len(v):6d} {np.median(v):10.1f} {v.mean():10.1f} {np.percentile(v, 90):10.1f} {v.max():10.1f}")
 print(f"gaps per evaluation: {tot / nev:.1f} us; kernels other than the task-queue launch per evaluation: "
-      f"{sum(np.sum(v) for k, v in dur.items() if k != 'dag_kernel') / 1e3 / nev:.1f} us; task-queue launch mean {np.mean(dur['dag_kernel']) / 1e3:.1f} us")
+      f"{sum(np.sum(v) for k, v in dur.items() if k != 'dag_kernel') / 1e3 / nev:.1f} us" +
+      (f"; task-queue launch mean {np.mean(dur['dag_kernel']) / 1e3:.1f} us" if "dag_kernel" in dur else ""))
+print("launches per evaluation:", " ".join(f"{k}={len(v) / nev:.1f}" for k, v in sorted(dur.items(), key=lambda kv: -len(kv[1])) if len(v) >= nev // 2))
