@@ -220,6 +220,7 @@ struct StreamPool {
 static StreamPool g_stream_pool;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int DAG_MIN_BLOCKS_FIT = 12;  // a fit's evaluations (and `extend`, which repeats them bit for bit) use the task queue from this many 128-blocks on
 
 // theta (log space) -> clamped linear-space parameters (fit.rs:94-96)
 static void theta_to_params(const double* theta, const double* lo, const double* hi, int d, EvalParams* P) {
@@ -443,7 +444,7 @@ struct Problem : ProblemBase {
   bool dry_ = false;                        // walk the evaluation without launching (schedule construction)
   bool adhoc_ = false;                      // GEMM launches bypass the per-evaluation schedule table
   bool small_ = false;                      // np = 128, d <= 32: one evaluation = ONE launch (small_eval_kernel), everything in the LDS
-  bool like_fit_ = false;                   // path selection of a fit (task queue from 8 blocks on) although there is one slot
+  bool like_fit_ = false;                   // path selection of a fit (task queue from DAG_MIN_BLOCKS_FIT blocks on) although there is one slot
   // HBEGP_HOSTIO (default 1): an evaluation is driven through the slot's pinned blocks -- the first kernel reads the parameters
   // there and prepares the device-side blocks (EvalPrologue), the last one copies the results back and publishes the
   // evaluation's serial number, which the host thread spins on.  0: parameter copy + reset kernel + memset in front, a result
@@ -555,7 +556,9 @@ struct Problem : ProblemBase {
     const int dag_env = env_int("HBEGP_DAG", -1);
     // measured (config M data, launches vs task queue): one evaluation alone n=1536: 0.75 / 0.78 ms, 2048: 1.05 / 1.02, 4096: 2.89 / 2.19,
     // 8192: 12.7 / 9.9; three concurrent optimiser runs (fits/s) n=512: 21.1 / 19.6, 1024: 11.35 / 11.48, 1536: 6.80 / 7.95, 4096: 1.29 / 1.58
-    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", (n_slots >= 2 || like_fit_) ? 8 : 16);
+    // round 4 (faster diagonal block, evaluations driven through pinned memory): three runs side by side, fits/s, launches / task
+    // queue: n=1024: 14.4 / 13.4, 1536: 7.95 / 8.7, 2048: 5.3 / 6.0 -- the queue from 12 blocks on (round 3: 8)
+    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", (n_slots >= 2 || like_fit_) ? DAG_MIN_BLOCKS_FIT : 16);
     dag_ = (dag_env < 0 ? np / NB >= dag_min_blocks : dag_env != 0) && !adhoc_ && np / NB >= 2;
     if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
@@ -1887,10 +1890,10 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
   hbegp_ctx one;
   one.devs = {ctx->devs[0]};
   // One order of operations for one theta: the evaluation runs the way a fit's evaluations do at this size -- through the task
-  // queue from 8 blocks on (its K^-1 split gives the undivided tiles' bits, DAGF_CINIT), as ad-hoc launches below that (a tile's
+  // queue from 12 blocks on (its K^-1 split gives the undivided tiles' bits, DAGF_CINIT), as ad-hoc launches below that (a tile's
   // arithmetic does not depend on how the launch is scheduled).
   const int dag_env = env_int("HBEGP_DAG", -1);
-  const bool queue_like_fit = (dag_env < 0 ? round_up(n, NB) / NB >= env_int("HBEGP_DAG_MIN_BLOCKS", 8) : dag_env != 0) && round_up(n, NB) / NB >= 2;
+  const bool queue_like_fit = (dag_env < 0 ? round_up(n, NB) / NB >= env_int("HBEGP_DAG_MIN_BLOCKS", DAG_MIN_BLOCKS_FIT) : dag_env != 0) && round_up(n, NB) / NB >= 2;
   Problem<T> prob(&one, X, y, n, d, nu, 1, !queue_like_fit && env_int("HBEGP_EXTEND_SCHED", 0) == 0, true);
   const int p = d + 2;
   Slot<T>& s = prob.slots[0][0];
