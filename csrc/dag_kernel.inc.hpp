@@ -302,6 +302,88 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
       }
 }
 
+// The chain's tile (DAG_GEMM_32x64, engine.hpp): 32 x 64 outputs, one 16x16 block per wave (2 x 4 wave grid), contraction in
+// passes of at most 128 elements.  All operand loads of a pass are issued at once (12 16-byte loads per thread in f64), land in
+// the LDS as [outer][k] rows, one barrier, then every wave runs its chain of dependent MFMA steps (32 for a 128-deep pass:
+// ~0.9 us with two waves per SIMD).  The staged 64x64 tile spends 5.8-6.1 us on the same 128-deep product (1.7 us of MFMA per
+// wave, eight stage barriers, two-stage prefetch); between two diagonal blocks that is paid twice.
+template <typename T, typename PullFn, typename FetchFn>
+__device__ __forceinline__ void dag_gemm_tile_chain(int flags, int row0, int col0, int kbeg, int kend, T* __restrict__ W1,
+                                                    T* __restrict__ W2, T* __restrict__ W3, int ld, char* smem_raw, PullFn pull,
+                                                    FetchFn fetch) {
+  using C = Cfg<T>;
+  using vec_t = typename C::vec_t;
+  using acc_t = typename C::acc_t;
+  constexpr int TA = 32, TB = 64, KC = 128, VEC = C::VEC, NT = 512;
+  constexpr int SK = KC + 4;               // LDS row stride (rows stay 16-byte aligned)
+  constexpr int CPR = KC / VEC;            // 16-byte chunks per row of a pass
+  constexpr int RPP = NT / CPR;            // rows per load pass
+  constexpr int NLOAD = (TA + TB) / RPP;   // loads per thread per pass (f64: 12, f32: 6)
+  static_assert(NT % CPR == 0 && (TA + TB) % RPP == 0 && TA % RPP == 0, "the load passes tile the operand rows");
+  static_assert((size_t)(TA + TB) * SK * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "both operands of a pass fit in front of the control words");
+  const T* Ag = (flags & DAGF_A3) ? W3 : ((flags & DAGF_ABUF) ? W2 : W1);
+  const T* Bg = (flags & DAGF_B3) ? W3 : ((flags & DAGF_BBUF) ? W2 : W1);
+  T* Cg = (flags & DAGF_C3) ? W3 : ((flags & DAGF_CBUF) ? W2 : W1);
+  T* lds = reinterpret_cast<T*>(smem_raw);  // [TA + TB][SK]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lc = (t % CPR) * VEC, lr = t / CPR;
+  const bool accum = (flags & DAGF_ACC) != 0, neg = (flags & DAGF_NEG) != 0;
+  const int er0 = row0 + wm * 16, ec = col0 + wn * 16 + (lane & 15);
+  T cold[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) cold[r] = accum ? Cg[(size_t)(er0 + C::crow(lane, r)) * ld + ec] : T(0);
+  acc_t acc = acc_t{0, 0, 0, 0};
+  constexpr bool CHUNKED = sizeof(T) == 4;
+  double tot[4] = {0, 0, 0, 0};
+  const int fa = (wm * 16 + (lane & 15)) * SK + (lane >> 4), fb = (TA + wn * 16 + (lane & 15)) * SK + (lane >> 4);
+  bool hooked = false;
+  for (int k0 = kbeg; k0 < kend; k0 += KC) {
+    const int kc = min(KC, kend - k0);
+    vec_t v[NLOAD];
+    const bool in_range = lc < kc;
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) {
+      const int row = q * RPP + lr;  // < TA: a row of A, else a row of B (uniform per q: TA % RPP == 0)
+      const T* src = (q * RPP < TA) ? Ag + (size_t)(row0 + row) * ld + k0 + lc : Bg + (size_t)(col0 + row - TA) * ld + k0 + lc;
+      v[q] = in_range ? *reinterpret_cast<const vec_t*>(src) : vec_t{};
+    }
+    if (!hooked) pull();
+    if (k0 != kbeg) __syncthreads();  // the previous pass's fragments have been read
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) C::lds_store(lds + (q * RPP + lr) * SK + lc, v[q]);
+    if (!hooked) fetch();
+    hooked = true;
+    __syncthreads();
+    const int nsteps = kc / 4;
+#pragma unroll 8
+    for (int s4 = 0; s4 < nsteps; ++s4) {
+      acc = C::mfma(lds[fa + 4 * s4], lds[fb + 4 * s4], acc);
+      if constexpr (CHUNKED) {
+        if ((k0 + 4 * s4 + 4) % F32_CHUNK == 0) {  // fp64 totals at the same absolute boundaries as the staged tiles
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[r] += (double)acc[r];
+          acc = acc_t{0, 0, 0, 0};
+        }
+      }
+    }
+  }
+  if (!hooked) { pull(); fetch(); }
+  if constexpr (CHUNKED) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tot[r] += (double)acc[r];  // what a last partial chunk holds (zeros otherwise)
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T vv;
+    if constexpr (CHUNKED) vv = (T)tot[r];
+    else vv = acc[r];
+    if (neg) vv = -vv;
+    if (accum) vv += cold[r];
+    gstore<true>(Cg + (size_t)(er0 + C::crow(lane, r)) * ld + ec, vv);
+  }
+}
+
 // ---- the launches around the factorisation as tasks: SAME arithmetic per element as kmat_kernel, trmv_n_kernel,
 // trmv_t_kernel, alpha_reduce_kernel and lml_final_kernel (kernels.hip), only the thread -> element mapping is carried
 // over to 512-thread workgroups (two 256-thread halves).  Anything another workgroup of this launch reads is stored
@@ -617,6 +699,8 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
         dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch);
       } else if (kind == DAG_GEMM_64x64) {
         dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch);
+      } else if (kind == DAG_GEMM_32x64) {
+        dag_gemm_tile_chain<T>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), g.ld, smem_raw, pull, fetch);
       } else if constexpr (MODE == DAG_MODE_FULL) {
         if (kind == DAG_KMAT) {
           dag_kmat_tile<T>(g, row0, col0, W1, smem_raw);

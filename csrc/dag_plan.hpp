@@ -76,6 +76,7 @@ struct DagCosts {
   double overhead = 1.5 + 4.0;
   double per128_big = 7.9;
   double per128_small = 3.9;
+  double per128_chain = 1.5;  // 32x64 one-shot tile: one dependent MFMA chain per wave
   double kmat = 9.0;  // one 128x64 kernel-matrix tile (fp64 exp/sqrt bound: 36 us for the 1056 tiles of n=4096 on 256 CUs)
 };
 
@@ -94,7 +95,9 @@ class DagBuilder {
   // right-looking plan: widest column range of a grouped update (measured at n = 4096, fit+predict/s: 4 -> 1.50, 8 -> 1.53,
   // 16 -> 1.53, 32 -> 1.57) and how many block columns ahead of the chain are updated column by column (1 -> 1.57, 2 -> 1.53,
   // 3 -> 1.51; one evaluation alone: 2.21 / 2.19 ms)
-  void set_rl(int group, int near, bool lauum_split = true) { rl_group_ = std::max(1, group); rl_near_ = std::max(1, near); rl_lauum_split_ = lauum_split; }
+  void set_rl(int group, int near, bool lauum_split = true, bool chain32 = true) {
+    rl_group_ = std::max(1, group); rl_near_ = std::max(1, near); rl_lauum_split_ = lauum_split; rl_chain32_ = chain32;
+  }
   // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
   // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
   // carries the inverse (whole matrix only; the factor L lives in W3)
@@ -123,6 +126,7 @@ class DagBuilder {
   int crit_rows_ = 1;
   int rl_group_ = 32, rl_near_ = 1;
   bool rl_lauum_split_ = true;
+  bool rl_chain32_ = true;   // right-looking plan: the two products between consecutive diagonal blocks as 32x64 one-shot tiles
   DagPlan plan_;
   DagCosts cost_;
 
@@ -163,7 +167,8 @@ class DagBuilder {
   struct Tile { int kind, bi, bj, row0, col0, ka, kb; };
 
   // the tiles of one product, block row by block row (deepest contraction first inside a row)
-  std::vector<Tile> tiles_of(const Op& op, bool small) {
+  // chain: the product sits between two consecutive diagonal blocks (right-looking plan): 32x64 one-shot tiles (DAG_GEMM_32x64)
+  std::vector<Tile> tiles_of(const Op& op, bool small, bool chain = false) {
     std::vector<Tile> tiles;
     for (int bi = op.r0; bi < op.r1; ++bi) {
       const size_t row_begin = tiles.size();
@@ -186,7 +191,11 @@ class DagBuilder {
               if (diag && ti < tj) continue;  // strictly upper 64-tile of a symmetric result
               int ka, kb;
               krange(ti, ti, &ka, &kb);
-              tiles.push_back({DAG_GEMM_64x64, bi, bj, ti * 64, tj * 64, ka * 64, kb * 64});
+              if (chain && !(op.flags & (DAGF_AKM | DAGF_BKM | DAGF_CINIT | DAGF_CKINV))) {
+                for (int h32 = 0; h32 < 2; ++h32) tiles.push_back({DAG_GEMM_32x64, bi, bj, ti * 64 + 32 * h32, tj * 64, ka * 64, kb * 64});
+              } else {
+                tiles.push_back({DAG_GEMM_64x64, bi, bj, ti * 64, tj * 64, ka * 64, kb * 64});
+              }
             }
           } else {
             int ka, kb;
@@ -221,7 +230,7 @@ class DagBuilder {
     t.row0 = tl.row0; t.col0 = tl.col0;
     t.kbeg = tl.ka / bk_ * bk_;
     t.kend = (tl.kb + bk_ - 1) / bk_ * bk_;
-    *cost_us = cost_.overhead + (t.kend - t.kbeg) / 128.0 * (tl.kind == DAG_GEMM_128x64 ? cost_.per128_big : cost_.per128_small);
+    *cost_us = cost_.overhead + (t.kend - t.kbeg) / 128.0 * (tl.kind == DAG_GEMM_128x64 ? cost_.per128_big : (tl.kind == DAG_GEMM_32x64 ? cost_.per128_chain : cost_.per128_small));
     return t;
   }
   static int count_row(const std::vector<Tile>& tiles, int bi) {
@@ -454,7 +463,7 @@ class DagBuilder {
         Op t{};
         t.flags = DAGF_BBUF | DAGF_C3;  // A = W1, B = W2 (X_kk), C = W3
         t.k0 = k; t.k1 = k + 1; t.klim = 1; t.tri_b = true;
-        const std::vector<Tile> tt = tiles_of(single_tile(t, i, k), i - k <= NEAR);
+        const std::vector<Tile> tt = tiles_of(single_tile(t, i, k), i - k <= NEAR, rl_chain32_ && i == k + 1);
         const int c = new_counter();
         lc[i][k] = DagGate{c, (int)tt.size()};
         const int nd = node_of[i][k];
@@ -475,7 +484,8 @@ class DagBuilder {
           u.flags = DAGF_A3 | DAGF_B3 | DAGF_NEG | DAGF_ACC;  // A = B = W3 (L), C = W1
           u.lower = (i == j);
           u.k0 = k0; u.k1 = k + 1;
-          const std::vector<Tile> ut = tiles_of(single_tile(u, i, j), single && j - k <= NEAR && i - k <= NEAR + 1);
+          const std::vector<Tile> ut = tiles_of(single_tile(u, i, j), single && j - k <= NEAR && i - k <= NEAR + 1,
+                                                rl_chain32_ && single && i == k + 1 && j == k + 1);
           const int c = new_counter();
           for (const Tile& tl : ut) {
             const DagTask tk = make(u, tl, &cu);
@@ -708,6 +718,10 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     // beta = 1, alpha = +1 and a non-empty contraction range (an empty one would store zeros over the first part's sums on the
     // 128x64 path, dag_gemm_tile); f32 problems never split (an f32 partial sum would be rounded on its way through memory):
     // build_lauum splits at the f64 stage depth only.
+    if (t.kind == DAG_GEMM_32x64 && (t.flags & (DAGF_AKM | DAGF_BKM | DAGF_CINIT | DAGF_CKINV))) {
+      snprintf(buf, sizeof buf, "task %d: the 32x64 one-shot tile reads both operands [outer][k] and writes W1/W2/W3 (flags %x)", i, t.flags);
+      return buf;
+    }
     if ((t.kind == DAG_GEMM_128x64 || t.kind == DAG_GEMM_64x64) && (t.flags & DAGF_CINIT)) {
       if (!(t.flags & DAGF_ACC) || (t.flags & DAGF_NEG) || t.kend <= t.kbeg) {
         snprintf(buf, sizeof buf, "task %d: DAGF_CINIT needs DAGF_ACC, no DAGF_NEG and a non-empty contraction range (flags %x, k [%d, %d))", i,
@@ -735,8 +749,8 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     // footprint
     struct Acc { int buf, r, c; bool write; };
     std::vector<Acc> accs;
-    auto rect = [&](int bufi, int r0, int r1, int c0, int c1, bool write) {  // element ranges
-      for (int r = r0 / 64; r < (r1 + 63) / 64; ++r)
+    auto rect = [&](int bufi, int r0, int r1, int c0, int c1, bool write) {  // element ranges; cells of 32 rows x 64 columns
+      for (int r = r0 / 32; r < (r1 + 31) / 32; ++r)
         for (int c = c0 / 64; c < (c1 + 63) / 64; ++c) accs.push_back({bufi, r, c, write});
     };
     auto cell = [&](int bufi, int r, int c, bool write) { accs.push_back({bufi, r, c, write}); };
@@ -755,7 +769,7 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
       const int np = nblocks_total * 128, i0 = t.row0 * 256, i1 = std::min(i0 + 256, np);
       for (int r = i0 / 64; r < i1 / 64; ++r)
         for (int c = t.col0 / 64; c < t.col0 / 64 + 2; ++c)
-          if (r >= c) cell(1, r, c, false);
+          if (r >= c) rect(1, r * 64, r * 64 + 64, c * 64, c * 64 + 64, false);
       for (int q = i0 / 32; q < i1 / 32; ++q) cell(2, q, 0, false);
       cell(3, t.row0, t.col0 / 128, true);
     } else if (t.kind == DAG_ALPHA_REDUCE) {
@@ -767,7 +781,7 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     } else if (t.kind == DAG_LML_FINAL) {
       for (int b = 0; b < (nblocks_total * 128 + 255) / 256; ++b) cell(5, b, 0, false);
     } else {
-      const int ta = t.kind == DAG_GEMM_128x64 ? 128 : 64, tb = 64;
+      const int ta = t.kind == DAG_GEMM_128x64 ? 128 : (t.kind == DAG_GEMM_32x64 ? 32 : 64), tb = 64;
       const int ab = (t.flags & DAGF_A3) ? 7 : ((t.flags & DAGF_ABUF) ? 1 : 0), bb = (t.flags & DAGF_B3) ? 7 : ((t.flags & DAGF_BBUF) ? 1 : 0);
       const int cb = (t.flags & DAGF_CKINV) ? 6 : ((t.flags & DAGF_C3) ? 7 : ((t.flags & DAGF_CBUF) ? 1 : 0));
       if (t.kend <= t.kbeg) return "empty contraction range";

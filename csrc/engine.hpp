@@ -93,6 +93,11 @@ enum : uint16_t {
   DAG_TRMV_T = 5,        // row0 = 256-row chunk index, col0 = first of 128 columns of the chunk's partial X^T w
   DAG_ALPHA_REDUCE = 6,  // col0 = 256-column block index: alpha, partial sums of y^T alpha and log diag(L)
   DAG_LML_FINAL = 7,
+  // round 4: a 32x64 output tile whose operands (at most 128 contraction elements at a time, both stored [outer][k]) are
+  // fetched in ONE shot -- the two products between consecutive diagonal blocks of the right-looking plan (L(k+1,k) =
+  // A(k+1,k) X_kk^T and A(k+1,k+1) -= L(k+1,k) L(k+1,k)^T), where a tile's latency counts and its throughput does not.
+  // Same accumulation order per element as the other tiles (k ascending in MFMA steps of four): same bits.
+  DAG_GEMM_32x64 = 8,
 };
 enum : uint16_t {
   DAGF_ABUF = 1,   // operand A lives in W2 (else W1)

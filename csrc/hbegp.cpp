@@ -597,12 +597,13 @@ struct Problem : ProblemBase {
       // 9.9 ms recursion / right-looking, 12288: 31.4 / 32.0, 16384: 72.3 / 75.5).
       dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
       static std::mutex cache_mu;
-      static std::map<std::array<int, 12>, std::shared_ptr<const DagPlan>> cache;
+      static std::map<std::array<int, 13>, std::shared_ptr<const DagPlan>> cache;
       auto plan_for = [&](int nwg) {
-        std::array<int, 12> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
+        std::array<int, 13> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
                                    env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                    env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1),
-                                   env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
+                                   env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0),
+                                   env_int("HBEGP_DAG_CHAIN32", 1)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
         std::shared_ptr<const DagPlan> cached;
         {
           std::lock_guard<std::mutex> lk(cache_mu);
@@ -611,7 +612,7 @@ struct Problem : ProblemBase {
         }
         if (!cached) {
           DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5]);
-          builder.set_rl(key[9], key[10], key[11] != 0);
+          builder.set_rl(key[9], key[10], key[11] != 0, key[12] != 0);
           cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_, dag_lauum_, dag_rl_));
           std::lock_guard<std::mutex> lk(cache_mu);
           if (cache.size() > 64) cache.clear();
