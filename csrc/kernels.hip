@@ -1084,7 +1084,8 @@ __device__ __forceinline__ void eval_prologue(const EvalParams* __restrict__ P, 
   static_assert(sizeof(EvalParams) % 8 == 0 && PW <= 256, "EvalParams is copied as 8-byte words by one workgroup");
   if (t < PW) reinterpret_cast<unsigned long long*>(pro.dP)[t] = reinterpret_cast<const unsigned long long*>(P)[t];
   poison_out(pro.out, t);
-  for (int i = t; i < pro.ctrl_words; i += 256) pro.ctrl[i] = 0;
+  int4* c4 = reinterpret_cast<int4*>(pro.ctrl);  // hipMalloc'd, a whole number of 16-byte words (hbegp.cpp: dag_ctrl_bytes)
+  for (int i = t; i < pro.ctrl_words / 4; i += 256) c4[i] = int4{0, 0, 0, 0};
 }
 
 // 64x64 tile per workgroup; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.  NU2: the Matern order at
@@ -1106,9 +1107,15 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
   const int li = tri_row(blockIdx.x), lj = blockIdx.x - li * (li + 1) / 2;
   const int i0 = li * 64, j0 = lj * 64;
   const int t = threadIdx.x;
+  // the parameters once per workgroup: in an evaluation driven through pinned memory P is a host block, and every read of it is
+  // an uncached round trip over the host link (per-thread reads made the launch 10 us longer at n=4096)
+  __shared__ double sp[MAXP];
+  if (t < d + 2) sp[t] = reinterpret_cast<const double*>(P)[t];
+  static_assert(offsetof(EvalParams, noise) == 0 && offsetof(EvalParams, amp) == 8 && offsetof(EvalParams, ell) == 16, "EvalParams: noise, amp, ell[]");
+  __syncthreads();
   for (int e = t; e < 64 * d; e += 256) {
     const int row = e / d, k = e - row * d;
-    const T ell = (T)P->ell[k];  // A::from_f (matern_kernel.rs:50)
+    const T ell = (T)sp[2 + k];  // A::from_f (matern_kernel.rs:50)
     const int gi = i0 + row, gj = j0 + row;
     xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] / ell : T(0);  // matern_kernel.rs:51-60
     xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
@@ -1134,7 +1141,7 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
         acc[r][c] += df * df;
       }
   }
-  const T amp = (T)P->amp, noise = (T)P->noise;
+  const T amp = (T)sp[1], noise = (T)sp[0];
   typedef T vec4 __attribute__((ext_vector_type(4)));
   if (i0 + 64 <= n && j0 + 64 <= n) {
     const bool dtile = li == lj;
