@@ -98,6 +98,11 @@ class DagBuilder {
   void set_rl(int group, int near, bool lauum_split = true, bool chain32 = true) {
     rl_group_ = std::max(1, group); rl_near_ = std::max(1, near); rl_lauum_split_ = lauum_split; rl_chain32_ = chain32;
   }
+  // right-looking plan, round 4: the inverse of the factor and K^-1 follow the diagonal chain row by row (rl_progressive)
+  // instead of by divide and conquer behind it
+  void set_rl_progressive(bool on, int unear = -1, int knear = -1, bool small_tiles = false) {
+    rl_prog_ = on; prog_unear_ = unear; prog_knear_ = knear; prog_small_ = small_tiles;
+  }
   // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
   // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
   // carries the inverse (whole matrix only; the factor L lives in W3)
@@ -126,6 +131,9 @@ class DagBuilder {
   int crit_rows_ = 1;
   int rl_group_ = 32, rl_near_ = 1;
   bool rl_lauum_split_ = true;
+  bool rl_prog_ = false;     // right-looking plan: row-progressive inverse and K^-1 (rl_progressive)
+  int prog_unear_ = -1, prog_knear_ = -1;  // single rows at the end of the U / K^-1 range lists (-1: rl_near_)
+  bool prog_small_ = false;  // 64x64 tiles for the rows of X and the last U updates before a row (measured: no gain, more tasks)
   bool rl_chain32_ = true;   // right-looking plan: the two products between consecutive diagonal blocks as 32x64 one-shot tiles
   DagPlan plan_;
   DagCosts cost_;
@@ -495,9 +503,128 @@ class DagBuilder {
         }
       }
     }
+    if (rl_prog_) {
+      rl_progressive(nb, lauum, leafc, lc);
+      return;
+    }
     // ---- the inverse of the factor, by the recursion's divide and conquer
     const Sub root = rl_inverse(0, nb, nodes, leafc);
     if (lauum) build_lauum(nb, root);
+  }
+
+  // Round 4.  With the divide-and-conquer inverse nothing of the bottom block rows of X = L^-1 exists before the LAST diagonal
+  // block is done (X21 = -X22 L21 X11 needs all of X22), and every tile of K^-1 = X^T X needs those rows: at n = 4096 a third of
+  // an evaluation's flops (all of K^-1, the top node's X21) could only start when the chain of diagonal blocks had ended -- 460 us
+  // of a 1.88 ms launch with every CU busy, after 1.4 ms in which the chain kept 30-130 of the 256 CUs busy.  Here both follow
+  // the chain row by row (block forward substitution), so that behind the last diagonal block only its own row is left:
+  //   U(i,j)   = sum_{k=j}^{i-1} L(i,k) X(k,j)      accumulated in W1(i,j) (dead since L(i,j) was formed) over ranges of k: a range
+  //                                                  [a,b) is applied once row b-1 of X is final -- wide ranges far from row i
+  //                                                  (deep, efficient tiles), single rows just before it (rl_groups' rule)
+  //   X(i,j)   = -X_ii U(i,j)                        as soon as diagonal block i is done; row i of X is then final
+  //   Kinv(i,j) += sum_{k in [a,b)} X(k,i)^T X(k,j)  for every range [a,b) of final rows, i, j < b
+  // f64: a continued sum starts its accumulators from the stored values (DAGF_CINIT), so every element is ONE k-ascending chain of
+  // MFMA accumulations whatever the ranges are; f32: the partial sums go through memory (rounded to f32 once per range).
+  // Same flops as the divide and conquer (sum_{i>j} (i - j) block products for the inverse).  Dependencies: leafc / lc as above;
+  //   rowfin[k]: row k of X final (implies every row above it: U(k,.) needed them);  uprev[i]: the last update of U(i,.) so far;
+  //   kprev: the previous range's K^-1 tiles.
+  void rl_progressive(int nb, bool lauum, const std::vector<DagGate>& leafc, const std::vector<std::vector<DagGate>>& lc) {
+    const int GROUP = rl_group_, NEAR = rl_near_;
+    const uint16_t cont = bk_ == 16 ? (uint16_t)(DAGF_ACC | DAGF_CINIT) : (uint16_t)DAGF_ACC;
+    std::vector<DagGate> rowfin(nb), uprev(nb);
+    std::vector<std::vector<std::pair<int, int>>> ugroups(nb);
+    const int UNEAR = prog_unear_ >= 0 ? prog_unear_ : NEAR, KNEAR = prog_knear_ >= 0 ? prog_knear_ : NEAR;
+    for (int i = 1; i < nb; ++i) ugroups[i] = rl_groups(i, GROUP, UNEAR);
+    const std::vector<std::pair<int, int>> kgroups = rl_groups(nb, GROUP, KNEAR);
+    DagGate kprev;
+    const double g0 = plan_.gflop;
+    double g_lauum = 0, cu = 0;
+    for (int k = 0; k < nb; ++k) {
+      // ---- row k of X
+      if (k == 0) {
+        rowfin[0] = leafc[0];
+      } else {
+        Op x{};
+        x.flags = DAGF_ABUF | DAGF_BKM | DAGF_CBUF | DAGF_NEG;  // A = W2 (X_kk), B = W1 (U, contraction along rows), C = W2
+        x.r0 = k; x.r1 = k + 1; x.c0 = 0; x.c1 = k; x.k0 = k; x.k1 = k + 1; x.klim = 3; x.tri_a = true;
+        const std::vector<Tile> xt = tiles_of(x, prog_small_);
+        const int c = new_counter();
+        for (const Tile& tl : xt) {
+          const DagTask tk = make(x, tl, &cu);
+          push(tk, {leafc[k], uprev[k]}, c, -1, cu);
+        }
+        rowfin[k] = DagGate{c, (int)xt.size()};
+      }
+      // ---- U(i, .) += L(i, a..k) X(a..k, .) for every row i whose list of ranges has one that ends with row k
+      for (int i = k + 1; i < nb; ++i) {
+        int a = -1;
+        for (const auto& gr : ugroups[i])
+          if (gr.second == k + 1) a = gr.first;
+        if (a < 0) continue;
+        const bool near = prog_small_ && (k + 1 - a) == 1 && i - k <= NEAR + 1;  // the last rows before row i: latency counts
+        const int c = new_counter();
+        int cnt = 0;
+        const std::vector<DagGate> waits = {lc[i][k], rowfin[k], uprev[i]};
+        if (a > 0) {  // columns left of the range: earlier ranges have started their sums
+          Op u{};
+          u.flags = (uint16_t)(DAGF_A3 | DAGF_BBUF | DAGF_BKM | cont);  // A = W3 (L), B = W2 (X, contraction along rows), C = W1
+          u.r0 = i; u.r1 = i + 1; u.c0 = 0; u.c1 = a; u.k0 = a; u.k1 = k + 1;
+          for (const Tile& tl : tiles_of(u, near)) {
+            const DagTask tk = make(u, tl, &cu);
+            push(tk, waits, c, -1, cu);
+            ++cnt;
+          }
+        }
+        {  // the range's own columns: first contribution (W1 holds the dead A(i,j) there), X(k,j) = 0 above the diagonal
+          Op u{};
+          u.flags = DAGF_A3 | DAGF_BBUF | DAGF_BKM;
+          u.r0 = i; u.r1 = i + 1; u.c0 = a; u.c1 = k + 1; u.k0 = a; u.k1 = k + 1; u.klim = 2; u.tri_b = true;
+          for (const Tile& tl : tiles_of(u, near)) {
+            const DagTask tk = make(u, tl, &cu);
+            push(tk, waits, c, -1, cu);
+            ++cnt;
+          }
+        }
+        uprev[i] = DagGate{c, cnt};
+      }
+      // ---- K^-1 += X(a..k, .)^T X(a..k, .) for the range of rows that ends with row k
+      if (lauum) {
+        int a = -1;
+        for (const auto& gr : kgroups)
+          if (gr.second == k + 1) a = gr.first;
+        if (a >= 0) {
+          const double gl0 = plan_.gflop;
+          const int c = new_counter();
+          int cnt = 0;
+          const std::vector<DagGate> waits = {rowfin[k], kprev};
+          if (a > 0) {
+            Op l{};
+            l.flags = (uint16_t)(DAGF_ABUF | DAGF_BBUF | DAGF_AKM | DAGF_BKM | DAGF_CKINV | cont);
+            l.r0 = 0; l.r1 = a; l.c0 = 0; l.c1 = a; l.lower = true; l.k0 = a; l.k1 = k + 1;
+            for (const Tile& tl : tiles_of(l, false)) {
+              const DagTask tk = make(l, tl, &cu);
+              push(tk, waits, c, -1, cu);
+              ++cnt;
+              plan_.n_lauum++;
+            }
+          }
+          {
+            Op l{};
+            l.flags = DAGF_ABUF | DAGF_BBUF | DAGF_AKM | DAGF_BKM | DAGF_CKINV;
+            l.r0 = a; l.r1 = k + 1; l.c0 = 0; l.c1 = k + 1; l.lower = true; l.k0 = a; l.k1 = k + 1; l.klim = 4; l.tri_a = true; l.tri_b = true;
+            for (const Tile& tl : tiles_of(l, false)) {
+              const DagTask tk = make(l, tl, &cu);
+              push(tk, waits, c, -1, cu);
+              ++cnt;
+              plan_.n_lauum++;
+            }
+          }
+          kprev = DagGate{c, cnt};
+          g_lauum += plan_.gflop - gl0;
+        }
+      }
+    }
+    (void)g0;
+    plan_.gflop_lauum = g_lauum;
   }
   Sub rl_inverse(int lo, int hi, const std::vector<RlNode>& nodes, const std::vector<DagGate>& leafc) {
     Sub out;

@@ -220,6 +220,7 @@ struct StreamPool {
 static StreamPool g_stream_pool;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int DAG_PROG_MAX_BLOCKS = 20;  // right-looking plan: the inverse and K^-1 follow the chain row by row up to this many 128-blocks
 constexpr int DAG_MIN_BLOCKS_FIT = 12;  // a fit's evaluations (and `extend`, which repeats them bit for bit) use the task queue from this many 128-blocks on
 
 // theta (log space) -> clamped linear-space parameters (fit.rs:94-96)
@@ -597,13 +598,21 @@ struct Problem : ProblemBase {
       // 9.9 ms recursion / right-looking, 12288: 31.4 / 32.0, 16384: 72.3 / 75.5).
       dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
       static std::mutex cache_mu;
-      static std::map<std::array<int, 13>, std::shared_ptr<const DagPlan>> cache;
+      static std::map<std::array<int, 17>, std::shared_ptr<const DagPlan>> cache;
       auto plan_for = [&](int nwg) {
-        std::array<int, 13> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
+        std::array<int, 17> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
                                    env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                    env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1),
                                    env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0),
-                                   env_int("HBEGP_DAG_CHAIN32", 1)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
+                                   env_int("HBEGP_DAG_CHAIN32", 1),
+                                   // row-progressive inverse and K^-1 (dag_plan.hpp rl_progressive) up to 20 blocks.  Measured (divide and
+                                   // conquer / progressive; one evaluation alone in ms, three-run fits per s): n=1536 0.65/0.65, 9.0/10.1;
+                                   // 2048 0.88/0.80, 6.4/7.1; 2560 1.12/1.05, 4.5/4.7; 3072 1.41/1.30, 3.37/3.21; 3584 1.75/1.67, 2.38/2.21;
+                                   // 4096 2.08/2.08, 1.67/1.55; C5 (n=2048 f32): 0.85/0.75 ms, 8.9/12.5 fits/s.  Above ~22 blocks the bulk
+                                   // tiles fill every CU and the chain's tasks wait for a free workgroup; a function of n alone, so that
+                                   // `extend` repeats a fit's evaluation bit for bit.
+                                   env_int("HBEGP_DAG_PROG", np / NB <= DAG_PROG_MAX_BLOCKS ? 1 : 0),
+                                   env_int("HBEGP_DAG_PROG_UNEAR", -1), env_int("HBEGP_DAG_PROG_KNEAR", -1), env_int("HBEGP_DAG_PROG_SMALL", 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
         std::shared_ptr<const DagPlan> cached;
         {
           std::lock_guard<std::mutex> lk(cache_mu);
@@ -613,6 +622,7 @@ struct Problem : ProblemBase {
         if (!cached) {
           DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5]);
           builder.set_rl(key[9], key[10], key[11] != 0, key[12] != 0);
+          builder.set_rl_progressive(key[13] != 0, key[14], key[15], key[16] != 0);
           cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_, dag_lauum_, dag_rl_));
           std::lock_guard<std::mutex> lk(cache_mu);
           if (cache.size() > 64) cache.clear();
@@ -2280,8 +2290,9 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0 || nwg < 0) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
   DagBuilder builder(bk, small_h, nwg, (fine & 1) != 0);
+  builder.set_rl_progressive((fine & 16) != 0);
   // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too; bit 2: the K^-1 = X^T X tiles behind the recursion;
-  // bit 3: the right-looking plan
+  // bit 3: the right-looking plan; bit 4: its row-progressive inverse and K^-1
   DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0, (fine & 4) != 0, (fine & 8) != 0);
   // fault injection for the validator's own test: HBEGP_DAG_TEST_FAULT = "drop:<i>" (task i loses its first wait) or
   // "move:<i>:<j>" (task i is moved to queue position j)

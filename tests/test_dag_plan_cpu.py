@@ -73,6 +73,35 @@ def test_right_looking_plans_are_sound_for_every_block_count(nb):
     assert rc == 0 and (ref is None or rec["gflop"] == pytest.approx(ref, rel=1e-12))
 
 
+@pytest.mark.parametrize("nb", list(range(1, 14)) + [16, 17, 20, 24, 31, 32, 33, 48])
+def test_row_progressive_plans_are_sound_for_every_block_count(nb):
+    # fine bit 4: right-looking plan whose inverse of the factor and K^-1 follow the diagonal chain row by row (round 4; the
+    # default up to 20 blocks): same flops as the divide and conquer, sound for every ordering
+    _, dc = plan(nb, 16, 4, 96, 1 | 4 | 8)
+    for bk in (16, 32):
+        for small_h, nwg, fine in [(4, 96, 1 | 4 | 8 | 16), (4, 256, 1 | 4 | 8 | 16), (8, 0, 1 | 8 | 16), (0, 3, 1 | 4 | 8 | 16), (4, 85, 4 | 8 | 16)]:
+            rc, info = plan(nb, bk, small_h, nwg, fine)
+            assert rc == 0, (nb, bk, small_h, nwg, fine, info["err"])
+            assert info["nleaf"] == nb
+            if fine & 4:
+                assert info["gflop"] == pytest.approx(dc["gflop"], rel=1e-12)
+
+
+def test_row_progressive_plan_leaves_little_behind_the_last_diagonal_block():
+    # n = 2048 on 256 workgroups: with the divide-and-conquer inverse a third of the flops can only start when the chain of
+    # diagonal blocks has ended; row by row the critical path and the simulated makespan are shorter
+    _, dc = plan(16, small_h=4, nwg=256, fine=1 | 4 | 8)
+    _, pr = plan(16, small_h=4, nwg=256, fine=1 | 4 | 8 | 16)
+    assert pr["crit_us"] < 0.9 * dc["crit_us"] and pr["sim_us"] < 0.9 * dc["sim_us"]
+
+
+@pytest.mark.parametrize("fault", ["drop:40", "drop:700", "drop:2000", "drop:2900", "move:2500:10", "move:900:100"])
+def test_checker_rejects_broken_row_progressive_plans(fault, monkeypatch):
+    monkeypatch.setenv("HBEGP_DAG_TEST_FAULT", fault)
+    rc, info = plan(16, small_h=4, nwg=96, fine=1 | 4 | 8 | 16)
+    assert rc == _lib.EINVAL and info["err"], fault
+
+
 def test_right_looking_plan_shortens_the_critical_path():
     # n = 4096: between two diagonal blocks the recursion has a product as deep as the node is wide, the right-looking plan
     # two 128-deep tiles (2.83 -> 2.03 ms simulated, 2.89 -> 2.19 ms measured for one evaluation)
