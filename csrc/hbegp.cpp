@@ -221,7 +221,7 @@ static StreamPool g_stream_pool;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 constexpr int DAG_PROG_MAX_BLOCKS = 20;  // right-looking plan: the inverse and K^-1 follow the chain row by row up to this many 128-blocks
-constexpr int DAG_MIN_BLOCKS_FIT = 12;  // a fit's evaluations (and `extend`, which repeats them bit for bit) use the task queue from this many 128-blocks on
+constexpr int DAG_MIN_BLOCKS_FIT = 6;   // evaluations (a fit's, `extend`'s, single ones) use the task queue from this many 128-blocks on
 
 // theta (log space) -> clamped linear-space parameters (fit.rs:94-96)
 static void theta_to_params(const double* theta, const double* lo, const double* hi, int d, EvalParams* P) {
@@ -559,7 +559,10 @@ struct Problem : ProblemBase {
     // 8192: 12.7 / 9.9; three concurrent optimiser runs (fits/s) n=512: 21.1 / 19.6, 1024: 11.35 / 11.48, 1536: 6.80 / 7.95, 4096: 1.29 / 1.58
     // round 4 (faster diagonal block, evaluations driven through pinned memory): three runs side by side, fits/s, launches / task
     // queue: n=1024: 14.4 / 13.4, 1536: 7.95 / 8.7, 2048: 5.3 / 6.0 -- the queue from 12 blocks on (round 3: 8)
-    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", (n_slots >= 2 || like_fit_) ? DAG_MIN_BLOCKS_FIT : 16);
+    // with the row-progressive plan (dag_plan.hpp rl_progressive): n=512: 29.8 / 28.6, 768: 19.9 / 20.7, 896: 17.0 / 18.3, 1024: 14.5 / 15.6,
+    // 1280: 10.3 / 12.3; one evaluation alone (ms): n=512 0.202 / 0.218, 768 0.301 / 0.302, 896 0.357 / 0.347, 1024 0.406 / 0.385,
+    // 1536 0.650 / 0.572 -- the queue from 6 blocks on, for fits and for single evaluations alike
+    const int dag_min_blocks = env_int("HBEGP_DAG_MIN_BLOCKS", DAG_MIN_BLOCKS_FIT);
     dag_ = (dag_env < 0 ? np / NB >= dag_min_blocks : dag_env != 0) && !adhoc_ && np / NB >= 2;
     if (refine_) dag_ = false;  // the refined panel solve exists as launches only (the task queue carries the f64 recursion)
     if (dag_) {
@@ -1901,7 +1904,7 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
   hbegp_ctx one;
   one.devs = {ctx->devs[0]};
   // One order of operations for one theta: the evaluation runs the way a fit's evaluations do at this size -- through the task
-  // queue from 12 blocks on (its K^-1 split gives the undivided tiles' bits, DAGF_CINIT), as ad-hoc launches below that (a tile's
+  // queue from 6 blocks on (its K^-1 split gives the undivided tiles' bits, DAGF_CINIT), as ad-hoc launches below that (a tile's
   // arithmetic does not depend on how the launch is scheduled).
   const int dag_env = env_int("HBEGP_DAG", -1);
   const bool queue_like_fit = (dag_env < 0 ? round_up(n, NB) / NB >= env_int("HBEGP_DAG_MIN_BLOCKS", DAG_MIN_BLOCKS_FIT) : dag_env != 0) && round_up(n, NB) / NB >= 2;
