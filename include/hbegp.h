@@ -29,10 +29,10 @@
  *     predictive variance relative to the amplitude: f64 1e-8 on lml, gradient, alpha, K^-1, mean and variance, or
  *     100 cond(K) eps where cond(K) puts LAPACK's own digits beyond that (corners of the box an optimiser visits).
  *     f32 (`--use-32`) 1e-4 on lml, gradient, mean and variance; alpha and K^-1 meet 1e-4 up to cond(K) ~ 7e4 on the paths a
- *     caller gets by default (the task queue's right-looking order: n >= 1024 inside a fit, n >= 2048 outside; the single
- *     launch up to n = 128), and max(1e-4, 2 x the deviation of LAPACK's own f32 path) otherwise -- between n = 129 and those
- *     thresholds f32 panel solves go through the explicit inverse of the whole left half, which costs K^-1 ~20 % more
- *     deviation at cond(K) = 7e4 (1.2e-4; LAPACK f32: 1.7e-4).  tests/test_gpu_fullsize.py holds both statements.
+ *     caller gets by default (the task queue's right-looking order from n = 641 on, for fits and single evaluations alike;
+ *     the single launch up to n = 128), and max(1e-4, 2 x the deviation of LAPACK's own f32 path) otherwise -- between
+ *     n = 129 and n = 640 f32 panel solves go through the explicit inverse of the whole left half, which costs K^-1 ~20 %
+ *     more deviation at cond(K) = 7e4 (1.2e-4; LAPACK f32: 1.7e-4).  tests/test_gpu_fullsize.py holds both statements.
  *   - Problems of at most 128 rows and 32 features (the reference's own regime, src/core/minimize.rs:118-120) take a path of
  *     their own: one evaluation is one launch that keeps K, L, L^-1, K^-1 and alpha in a compute unit's LDS, and one optimiser
  *     run of a fit is one persistent launch (evaluation + bounded L-BFGS step + capture on the device); the host only starts
