@@ -166,7 +166,7 @@ struct HostPool {
       }
     }
     void* p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocCoherent);  // fine-grained: a host thread spins on words the GPU writes (Problem::wait_eval)
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);  // fine-grained: a host thread spins on words the GPU writes (Problem::wait_eval)
     if (e != hipSuccess) throw HipError{e, "hipHostMalloc (pool)", __LINE__};
     return p;
   }
