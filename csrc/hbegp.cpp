@@ -1054,15 +1054,20 @@ struct Problem : ProblemBase {
       gemm(s, di, g, tm, PhaseTimer::LAUUM);
     }
     if (dry_) return;
+    bool fuse_grad = false;
     if (want_grad) {
       if (tm) tm->begin(PhaseTimer::GRAD);
-      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation
+      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation -- where the launch is a
+      // few hundred workgroups (latency-bound sizes).  Every workgroup drains its write-through partials before it takes its
+      // ticket (~2 us at the end of its life): with the 2,080 workgroups of n = 4096 queueing for the ~60 CUs the other two
+      // task-queue launches leave free that made the launch 138 -> 182 us; there the two tiny launches behind it are free.
+      fuse_grad = hostio && (np / 64) * (np / 64 + 1) / 2 <= 512;
       launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream,
-                          hostio ? s.tickets + 1 : nullptr, hostio ? s.hOut : nullptr);
+                          fuse_grad ? s.tickets + 1 : nullptr, fuse_grad ? s.hOut : nullptr);
       if (tm) tm->end();
     }
     if (hostio) {
-      if (!want_grad) launch_publish_out(s.dOut, s.hOut, s.dP, s.stream);
+      if (!want_grad || !fuse_grad) launch_publish_out(s.dOut, s.hOut, s.dP, s.stream);
       s.published = true;
     }
     CHECK_LAUNCHES();
