@@ -100,8 +100,8 @@ class DagBuilder {
   }
   // right-looking plan, round 4: the inverse of the factor and K^-1 follow the diagonal chain row by row (rl_progressive)
   // instead of by divide and conquer behind it
-  void set_rl_progressive(bool on, int unear = -1, int knear = -1, bool small_tiles = false) {
-    rl_prog_ = on; prog_unear_ = unear; prog_knear_ = knear; prog_small_ = small_tiles;
+  void set_rl_progressive(bool on, int unear = -1, int knear = -1, bool small_tiles = false, int ratio = 0) {
+    rl_prog_ = on; prog_unear_ = unear; prog_knear_ = knear; prog_small_ = small_tiles; prog_ratio_ = ratio;
   }
   // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
   // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
@@ -133,6 +133,7 @@ class DagBuilder {
   bool rl_lauum_split_ = true;
   bool rl_prog_ = false;     // right-looking plan: row-progressive inverse and K^-1 (rl_progressive)
   int prog_unear_ = -1, prog_knear_ = -1;  // single rows at the end of the U / K^-1 range lists (-1: rl_near_)
+  int prog_ratio_ = 0;       // 0: rl_groups' ranges (aligned powers of two); >= 2: ranges growing by this factor from the end
   bool prog_small_ = false;  // 64x64 tiles for the rows of X and the last U updates before a row (measured: no gain, more tasks)
   bool rl_chain32_ = true;   // right-looking plan: the two products between consecutive diagonal blocks as 32x64 one-shot tiles
   DagPlan plan_;
@@ -533,8 +534,25 @@ class DagBuilder {
     std::vector<DagGate> rowfin(nb), uprev(nb);
     std::vector<std::vector<std::pair<int, int>>> ugroups(nb);
     const int UNEAR = prog_unear_ >= 0 ? prog_unear_ : NEAR, KNEAR = prog_knear_ >= 0 ? prog_knear_ : NEAR;
-    for (int i = 1; i < nb; ++i) ugroups[i] = rl_groups(i, GROUP, UNEAR);
-    const std::vector<std::pair<int, int>> kgroups = rl_groups(nb, GROUP, KNEAR);
+    // ranges of [0, n) counted from the END: `near` single rows, then ranges growing by the factor prog_ratio_ (3, 12, 48 ... for
+    // 4), the rest in one piece -- unaligned, unlike rl_groups (prog_ratio_ = 0: rl_groups' aligned powers of two)
+    auto ranges_from_end = [&](int n, int near) {
+      std::vector<std::pair<int, int>> out;
+      int b = n;
+      for (int q = 0; q < near && b > 0; ++q) { out.push_back({b - 1, b}); --b; }
+      int len = std::max(1, prog_ratio_ - 1);
+      while (b > 0) {
+        int a = std::max(0, b - len);
+        if (a < len / 2 + 1) a = 0;  // do not leave a sliver at the front
+        out.push_back({a, b});
+        b = a;
+        len *= prog_ratio_;
+      }
+      std::reverse(out.begin(), out.end());
+      return out;
+    };
+    for (int i = 1; i < nb; ++i) ugroups[i] = prog_ratio_ >= 2 ? ranges_from_end(i, std::max(1, UNEAR)) : rl_groups(i, GROUP, UNEAR);
+    const std::vector<std::pair<int, int>> kgroups = prog_ratio_ >= 2 ? ranges_from_end(nb, std::max(1, KNEAR)) : rl_groups(nb, GROUP, KNEAR);
     DagGate kprev;
     const double g0 = plan_.gflop;
     double g_lauum = 0, cu = 0;
