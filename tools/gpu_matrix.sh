@@ -1,9 +1,11 @@
 #!/bin/bash
 # the GPU suite under the library's alternative configurations (each must be green): plan validation on every problem, eager
-# launches instead of graph replay, launch path everywhere, task queue everywhere
+# launches instead of graph replay, launch path everywhere, task queue everywhere; round 4: copy nodes + stream sync instead of the
+# pinned-memory protocol, divide-and-conquer / row-progressive inverse everywhere, 64x64 chain tiles, no LDS path, host-driven small fits
 OUT=gpurun_out/matrix
 mkdir -p $OUT
-for cfg in "HBEGP_DAG_VALIDATE=1" "HBEGP_NO_GRAPH=1" "HBEGP_DAG=0" "HBEGP_DAG=1" "HBEGP_DAG_RL=0"; do
+rm -f $OUT/progress.txt
+for cfg in "HBEGP_DAG_VALIDATE=1" "HBEGP_NO_GRAPH=1" "HBEGP_DAG=0" "HBEGP_DAG=1" "HBEGP_DAG_RL=0" "HBEGP_HOSTIO=0" "HBEGP_DAG_PROG=0" "HBEGP_DAG_PROG=1" "HBEGP_DAG_CHAIN32=0" "HBEGP_SMALL=0" "HBEGP_SMALL_FIT=0"; do
   name=$(echo $cfg | tr '=' '_')
   env $cfg timeout -k 10 900 python3 -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/$name.txt 2>&1
   echo "$cfg: $(tail -1 $OUT/$name.txt)" | tee -a $OUT/progress.txt
