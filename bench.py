@@ -552,6 +552,33 @@ def main():
                 "note": "fixed-work fits, 3 optimiser runs x 150 evaluations, best of the timed repetitions; M f64 is the headline (incl. predict)"}
         except Exception as e:  # the side line must never cost the headline
             out["f32_side_line"] = {"error": str(e)}
+        # the other BASELINE configurations at their full size (C3 is --workload C3, C5 the f32 line above): one evaluation alone
+        # and a fixed-work fit each, f64
+        try:
+            cfgs = {}
+            for cname in ("C1", "C2", "C4"):
+                log(f"  BASELINE config {cname}")
+                wc = synth.make_workload(cname)
+                pc = gpr.Problem(wc["X"], wc["y"], nu=2.5, ctx=ctx)
+                phc = pc.time_eval(wc["theta"], reps=5)
+                pc.close()
+                stc = synth.restart_points(cname, wc["lo"], wc["hi"], N_RESTARTS)
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    f = gpr.FittedKernel.new(wc["X"], wc["y"], wc["theta0"], wc["lo"], wc["hi"], stc, nu=2.5, ctx=ctx, maxeval=EVALS_PER_RUN, fixed_work=True)
+                    dt = time.perf_counter() - t0
+                    f.release()
+                    best = dt if best is None else min(best, dt)
+                nn = wc["X"].shape[0]
+                cfgs[f"{cname} n={nn} d={wc['X'].shape[1]}"] = {
+                    "eval_ms": phc["eval_graph_ms"], "fits_per_s": 1.0 / best,
+                    "fit_frac_of_fp64_peak": (N_RESTARTS + 1) * EVALS_PER_RUN * nn ** 3 * 1e-12 / best / PEAK_FP64_MFMA_TFLOPS}
+            out["baseline_configs_side_line"] = dict(cfgs, note="BASELINE.json configs[0], [1], [3] at full size, f64: one lml+gradient evaluation alone "
+                                                                "(graph replay) and fixed-work fits (3 runs x 150 evaluations, best of 2); parity at these sizes: "
+                                                                "tests/test_gpu_fullsize.py, tests/test_gpu_parity.py")
+        except Exception as e:
+            out["baseline_configs_side_line"] = {"error": str(e)}
         # small and mid n (the reference's own regime is n <= 200, minimize.rs:118-120): fixed-work fits/s, f64
         try:
             small = {}
