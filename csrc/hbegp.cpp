@@ -396,6 +396,7 @@ struct Slot {
   unsigned long long seq = 0;  // serial number of the last evaluation handed to the device (EvalParams::seq)
   bool ctrl_cleared = false;   // the evaluation's first kernel clears dag_ctrl itself (EvalPrologue): no memset node
   bool published = false;      // the evaluation ends with publish_out_kernel: the host may spin on hOut->seq
+  long long expect_ns = 0;     // how long the last published evaluation took from launch to publication (wait_eval sleeps through most of it)
 };
 
 struct ProblemBase {
@@ -1082,17 +1083,32 @@ struct Problem : ProblemBase {
   // stores into the pinned result block behind a system-scope fence; hipStreamSynchronize sleeps on an interrupt and wakes up
   // ~50 us late, which three optimiser runs pay 150 times each.  A kernel that faults never publishes: after two seconds the
   // thread falls back to hipStreamSynchronize, which reports the fault (or simply waits for a very long evaluation).
-  void wait_eval(Slot<T>& s) {
+  // Long evaluations are slept through first: the thread remembers how long this slot's last evaluation took (they are all
+  // alike) and, from 1.5 ms on, sleeps until an eighth of it (at least 300 us) before that: a fit at n = 4096 then keeps 1.4 cores busy
+  // instead of 4 (hipStreamSynchronize spins as well: 4 cores with HBEGP_HOSTIO=0 too; tools/cpu_cost_probe.py).  A sleep that ran past the end shortens the next one.  HBEGP_SPIN_ONLY=1: no sleeping.
+  void wait_eval(Slot<T>& s, std::chrono::steady_clock::time_point t_launch) {
     if (s.published) {
+      using namespace std::chrono;
+      static const bool spin_only = env_int("HBEGP_SPIN_ONLY", 0) != 0;
       const volatile unsigned long long* q = &s.hOut->seq;
-      const auto t0 = std::chrono::steady_clock::now();
+      if (!spin_only && s.expect_ns > 1500000) {  // below ~1.5 ms a timer's wake-up jitter (50-100 us) costs more than it saves: n=512 fits 29.7 -> 21.6 /s with a 0.4 ms threshold
+        const long long margin = std::max<long long>(300000, s.expect_ns / 8);  // concurrent runs stretch each other by a few per cent, unevenly
+        std::this_thread::sleep_until(t_launch + nanoseconds(s.expect_ns - margin));
+        if (*q == s.seq) {  // slept too long: the measurement below would include the oversleep
+          std::atomic_thread_fence(std::memory_order_acquire);
+          s.expect_ns = s.expect_ns * 9 / 10;
+          return;
+        }
+      }
+      const auto t0 = steady_clock::now();
       for (unsigned it = 1;; ++it) {
         if (*q == s.seq) {
           std::atomic_thread_fence(std::memory_order_acquire);
+          s.expect_ns = duration_cast<nanoseconds>(steady_clock::now() - t_launch).count();
           return;
         }
         __builtin_ia32_pause();
-        if ((it & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        if ((it & 4095u) == 0 && steady_clock::now() - t0 > seconds(2)) break;
       }
     }
     HIPCHECK(hipStreamSynchronize(s.stream));
@@ -1218,6 +1234,7 @@ struct Problem : ProblemBase {
     static const bool graphs_on = env_int("HBEGP_NO_GRAPH", 0) == 0;
     s.dag_variant = variant_now(di);
     s.hP->seq = ++s.seq;
+    const auto t_launch = std::chrono::steady_clock::now();
     if (use_graph && graphs_on) {
       hipGraphExec_t& ge = s.graph[s.dag_variant][target][want_grad ? 1 : 0];
       if (!ge) {
@@ -1238,7 +1255,7 @@ struct Problem : ProblemBase {
       enqueue_eval(s, di, target, want_grad, nullptr);
     }
     s.published = hostio_ && !small_ && !(dag_ && dag_full_ && !adhoc_);  // what enqueue_eval records when it is not replayed from a graph
-    wait_eval(s);
+    wait_eval(s, t_launch);
     s.last_target = target;
     const int p = d + 2;
     if (s.hOut->info < 0) {
