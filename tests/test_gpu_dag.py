@@ -223,3 +223,62 @@ def test_full_mode_queue_matches_launch_path(monkeypatch):
         assert r0 is not None and r1 is not None
         assert _close(r0[0], r1[0], 1e-13) and _close(r0[1], r1[1], 1e-13)
         assert _close(a0, a1, 1e-13) and _close(k0, k1, 1e-13) and _close(l0, l1, 1e-13)
+
+
+def _bits_equal(a, b):
+    (ra, (aa, ka, la)), (rb, (ab, kb, lb)) = a, b
+    return ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(aa, ab) and np.array_equal(np.tril(ka), np.tril(kb)) and np.array_equal(la, lb)
+
+
+@pytest.mark.parametrize("n,cfg,dtype", [(300, "M", np.float64), (800, "C2", np.float64), (1500, "M", np.float64), (2700, "M", np.float64), (1500, "C5", np.float32)])
+def test_round4_switches_do_not_change_a_bit(n, cfg, dtype, monkeypatch):
+    # Round 4 changed HOW an evaluation is driven and scheduled, not its arithmetic: (a) through pinned memory, with the gradient
+    # finalised and the lml formed by the last workgroup of a launch, or with copy nodes, separate finalise kernels and a
+    # stream synchronise (HBEGP_HOSTIO); (b) 32x64 one-shot tiles between two diagonal blocks or 64x64 staged tiles
+    # (HBEGP_DAG_CHAIN32: the same k-ascending accumulation per element).  lml, gradient, alpha, K^-1 and diag(L) bit for bit.
+    w = synth.make_workload(cfg, n=n)
+    X, y, theta = w["X"].astype(dtype), w["y"].astype(dtype), w["theta"].copy()
+    if dtype == np.float32:
+        theta[0] = theta[1] + math.log(0.5)
+    monkeypatch.delenv("HBEGP_DAG", raising=False)
+    base = None
+    for hostio, chain32 in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("HBEGP_HOSTIO", hostio)
+        monkeypatch.setenv("HBEGP_DAG_CHAIN32", chain32)
+        prob = gpr.Problem(X, y)
+        got = (prob.lml_with_gradient(theta), prob.results())
+        prob.close()
+        base = base or got
+        assert _bits_equal(base, got), (hostio, chain32)
+
+
+@pytest.mark.parametrize("n", [900, 1500, 2500])
+def test_row_progressive_plan_against_the_divide_and_conquer_inverse(n, monkeypatch):
+    # The inverse of the factor and K^-1 row by row behind the diagonal chain (the default up to 20 blocks, csrc/dag_plan.hpp
+    # rl_progressive) against the divide-and-conquer inverse: the same factor (bitwise: the Cholesky part of the plan is the same),
+    # another order of operations for X = L^-1 -- equal to 1e-11 of the largest entry, and both within 1e-8 of the oracle.  In f64
+    # the ranges a continued sum is cut into do not matter (DAGF_CINIT: one k-ascending chain per element): bit for bit.
+    w = synth.make_workload("M", n=n)
+    X, y, theta = w["X"], w["y"], w["theta"]
+    monkeypatch.delenv("HBEGP_DAG", raising=False)
+    monkeypatch.setenv("HBEGP_DAG_MIN_BLOCKS", "2")
+    out = {}
+    for name, env in (("dc", {"HBEGP_DAG_PROG": "0"}), ("prog", {"HBEGP_DAG_PROG": "1"}), ("prog3", {"HBEGP_DAG_PROG": "1", "HBEGP_DAG_PROG_RATIO": "3"})):
+        for k in ("HBEGP_DAG_PROG", "HBEGP_DAG_PROG_RATIO"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        prob = gpr.Problem(X, y)
+        out[name] = (prob.lml_with_gradient(theta), prob.results())
+        prob.close()
+    assert _bits_equal(out["prog"], out["prog3"])
+    (rd, (ad, kd, ld)), (rp, (ap, kp, lp)) = out["dc"], out["prog"]
+    assert np.array_equal(ld, lp)  # diag(L): the factor itself is the same computation
+    assert abs(rd[0] - rp[0]) <= 1e-11 * max(1.0, abs(rd[0]))
+    np.testing.assert_allclose(rp[1], rd[1], rtol=0, atol=1e-11 * max(1.0, np.abs(rd[1]).max()))
+    np.testing.assert_allclose(ap, ad, rtol=0, atol=1e-11 * max(1.0, np.abs(ad).max()))
+    np.testing.assert_allclose(np.tril(kp), np.tril(kd), rtol=0, atol=1e-11 * max(1.0, np.abs(kd).max()))
+    s2, c, ell = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:])
+    ref = O.lml_with_gradient(X, y, s2, c, ell, 2.5)
+    assert abs(rp[0] - ref["lml"]) <= 1e-8 * max(1.0, abs(ref["lml"]))
+    np.testing.assert_allclose(np.tril(kp), np.tril(ref["k_inv"]), rtol=0, atol=1e-8 * max(1.0, np.abs(ref["k_inv"]).max()))
