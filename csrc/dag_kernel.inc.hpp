@@ -55,10 +55,12 @@ static_assert(DAG_LDS_BYTES <= 163840, "the diagonal block and the control words
 // atomic on the queue head) once no operand load is left to issue, fetch() (wave 0: the entry's descriptor) before the last
 // stage, so that both round trips hide under the last MFMA stages and the entry is claimed only ~2 us before this workgroup is
 // free (claiming it a whole task earlier parks the chain's tasks behind bulk tiles: measured 2.05 -> 3.06 ms per evaluation).
+// -DDAG_STAMP_INNER (diagnostic build, tools/trace_inner.py): two more time stamps per tile task -- first stage in the LDS (the
+// first MFMA can start) and last MFMA issued -- packed into the trace's CU-id word (low 32 bits of the 100 MHz clock each).
 template <typename T, int TA, int TB, typename PullFn, typename FetchFn>
 __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int kbeg, int kend, T* __restrict__ W1,
                                               T* __restrict__ W2, T* __restrict__ W3, T* __restrict__ Kinv, int ld, char* smem_raw,
-                                              PullFn pull, FetchFn fetch) {
+                                              PullFn pull, FetchFn fetch, unsigned long long* inner = nullptr) {
   using C = Cfg<T>;
   using G = DagGeom<T, TA, TB>;
   using vec_t = typename C::vec_t;
@@ -256,6 +258,10 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
     }
     __syncthreads();
     read_frags(0, 0);
+#ifdef DAG_STAMP_INNER
+    unsigned long long st1 = 0;
+    if (inner && t == 0) st1 = __builtin_amdgcn_s_memrealtime();
+#endif
     int s = 0;
     for (; s + 3 < nstages; s += 2) {
       stage(0, true, ra0, rb0, true, ra1, rb1, true);
@@ -272,6 +278,9 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
       fetch();
       stage(0, false, ra0, rb0, false, ra1, rb1, false);
     }
+#ifdef DAG_STAMP_INNER
+    if (inner && t == 0) *inner = ((st1 & 0xffffffffull) << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
+#endif
   } else {
     pull();
     fetch();
@@ -690,15 +699,20 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
       }
       fetched = true;
     };
+#ifdef DAG_STAMP_INNER
+    unsigned long long* inner_stamp = g.trace ? g.trace + (size_t)this_idx * 5 + 4 : nullptr;
+#else
+    unsigned long long* inner_stamp = nullptr;
+#endif
     if (status == 0) {
       if (kind == DAG_LEAF) {
         dag_leaf_task<T>(W1, W2, g.ld, row0, static_cast<T*>(g.ldiag), g.info, smem_raw, g.leaf_dbg & 16);  // only the test bit: the timing bits stay with tools/leaf_bench
       } else if ((flags & DAGF_CKINV) && g.Kinv == nullptr) {
         // factorisation-only launch: the K^-1 tiles are not wanted
       } else if (kind == DAG_GEMM_128x64) {
-        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch);
+        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_64x64) {
-        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch);
+        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_32x64) {
         dag_gemm_tile_chain<T>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), g.ld, smem_raw, pull, fetch);
       } else if constexpr (MODE == DAG_MODE_FULL) {
@@ -762,7 +776,11 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
         unsigned xcc = 0, hwid = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+#ifndef DAG_STAMP_INNER
         g.trace[(size_t)this_idx * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+#else
+        (void)xcc; (void)hwid;
+#endif
       }
     }
     par ^= 1;
