@@ -68,6 +68,9 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   constexpr int VEC = C::VEC, BK = G::BK, SK = G::SK, SMA = G::SMA, SMB = G::SMB, NCHA = G::NCHA, NCHB = G::NCHB;
   constexpr int TMA = G::TMA, TMB = G::TMB, NT = G::NT;
 
+#ifdef DAG_HEAD_DELAY  /* diagnostic build: every tile task starts DAG_HEAD_DELAY x 64 cycles late -- does the fit rate follow the per-task fixed cost? */
+  for (int q = 0; q < DAG_HEAD_DELAY; ++q) __builtin_amdgcn_s_sleep(1);
+#endif
   const int akm = (flags & DAGF_AKM) ? 1 : 0, bkm = (flags & DAGF_BKM) ? 1 : 0;
   const T* Ag = (flags & DAGF_A3) ? W3 : ((flags & DAGF_ABUF) ? W2 : W1);
   const T* Bg = (flags & DAGF_B3) ? W3 : ((flags & DAGF_BBUF) ? W2 : W1);
