@@ -793,6 +793,9 @@ class DagBuilder {
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> running;
     std::vector<DagTask> out;
     out.reserve(nt);
+    std::vector<int> out_idx;      // original index of the task at each queue position
+    std::vector<double> start(nt, 0.0);
+    out_idx.reserve(nt);
     int idle = nwg_;
     double now = 0;
     while ((int)out.size() < nt) {
@@ -800,6 +803,8 @@ class DagBuilder {
         const int i = -ready.top().second;
         ready.pop();
         out.push_back(plan_.tasks[i]);
+        out_idx.push_back(i);
+        start[i] = now;
         running.push({now + plan_.tasks[i].cost * 0.1, i});
         --idle;
       }
@@ -819,10 +824,39 @@ class DagBuilder {
     }
     while (!running.empty()) { now = running.top().first; running.pop(); }
     if ((int)out.size() == nt) {
+      if (chain_bias_us_ > 0) {
+        // The queue is claimed IN ORDER: a chain task that becomes ready while entries in front of it are still unclaimed waits
+        // for every one of them to be claimed first (a full chip frees a workgroup every ~0.4 us).  Move the chain's tasks
+        // (diagonal blocks, the 32x64 tiles between them) forward by chain_bias_us_ of simulated time -- a workgroup then claims
+        // them early and waits for their dependencies instead -- but never in front of a task they depend on (the order stays
+        // topological: key(task) > key(every task that bumps a counter it waits for)).
+        std::vector<double> key(nt, 0.0), ckey(nc, -1e30);
+        for (int pos = 0; pos < nt; ++pos) {
+          const int i = out_idx[pos];
+          const DagTask& t = plan_.tasks[i];
+          const bool chain = t.kind == DAG_LEAF || t.kind == DAG_GEMM_32x64;
+          double k = start[i] - (chain ? chain_bias_us_ : 0.0);
+          for (int w = 0; w < t.nwait; ++w) k = std::max(k, ckey[t.wcnt[w]] + 1e-6);
+          key[i] = k;
+          for (int q = 0; q < DAG_MAXSIG; ++q)
+            if (t.sig[q] != DAG_NOSIG) ckey[t.sig[q]] = std::max(ckey[t.sig[q]], k);
+        }
+        std::vector<int> perm(nt);
+        for (int pos = 0; pos < nt; ++pos) perm[pos] = pos;
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[out_idx[a]] < key[out_idx[b]]; });
+        std::vector<DagTask> re;
+        re.reserve(nt);
+        for (int pos = 0; pos < nt; ++pos) re.push_back(out[perm[pos]]);
+        out.swap(re);
+      }
       plan_.tasks.swap(out);
       plan_.sim_us = now;
     }
   }
+  double chain_bias_us_ = 0.0;
+
+ public:
+  void set_chain_bias(double us) { chain_bias_us_ = us; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
