@@ -121,11 +121,12 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   // there; the loads' latency hides under the contraction -- it was a third of a 128-deep update's time)
   // The 64x64 tile keeps them in registers (8); the 128x64 tile (16: the kernel's diagonal block would spill) parks them in
   // the LDS behind the stage buffers until the epilogue.  Measured on the 128-deep 128x64 update: 13.8 -> 9.9 us.
-  const bool accum = (flags & DAGF_ACC) != 0;
-  const bool cinit = sizeof(T) == 8 && (flags & DAGF_CINIT) != 0;  // the old values start the accumulation (engine.hpp)
+  constexpr bool NOACC = TB == 128;  // the 128x128 tile: alpha * A B only (the plan never gives it beta = 1; dag_plan_validate checks)
+  const bool accum = !NOACC && (flags & DAGF_ACC) != 0;
+  const bool cinit = !NOACC && sizeof(T) == 8 && (flags & DAGF_CINIT) != 0;  // the old values start the accumulation (engine.hpp)
   constexpr bool PREFETCH_C = TA == 64 || (sizeof(T) == 8 && DAG_F64_KMUL > 1);
   constexpr int STASH_OFF = 2 * (G::LDSA + G::LDSB);  // in elements of T, behind [A buf0 | A buf1 | B buf0 | B buf1]
-  static_assert(PREFETCH_C || (size_t)(STASH_OFF + TA * TB) * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stash must fit in front of the control words");
+  static_assert(NOACC || PREFETCH_C || (size_t)(STASH_OFF + TA * TB) * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stash must fit in front of the control words");
   static_assert((size_t)STASH_OFF * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stage buffers must fit in front of the control words");
   T cold[PREFETCH_C ? TMA : 1][PREFETCH_C ? TMB : 1][4];
   if constexpr (PREFETCH_C) {
@@ -222,7 +223,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   if (nstages > 0) {
     load_stage(ra0, rb0);
     if (nstages > 1) load_stage(ra1, rb1);
-    if constexpr (!PREFETCH_C) {
+    if constexpr (!PREFETCH_C && !NOACC) {
       if (accum) {  // old values of the output tile -> LDS stash (each thread its own 16 slots, lane-contiguous)
         T cst[TMA][TMB][4];
         const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
@@ -307,7 +308,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
         if (neg) v = -v;
         if constexpr (PREFETCH_C) {
           if (accum && !cinit) v += cold[a][b][r];
-        } else {
+        } else if constexpr (!NOACC) {
           if (accum && !cinit) v += lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t];
         }
         gstore<true>(p, v);
@@ -716,6 +717,8 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
         dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_64x64) {
         dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
+      } else if (kind == DAG_GEMM_128x128) {
+        dag_gemm_tile<T, 128, 128>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_32x64) {
         dag_gemm_tile_chain<T>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), g.ld, smem_raw, pull, fetch);
       } else if constexpr (MODE == DAG_MODE_FULL) {

@@ -76,6 +76,7 @@ struct DagCosts {
   double overhead = 1.5 + 4.0;
   double per128_big = 7.9;
   double per128_small = 3.9;
+  double per128_big128 = 15.0;  // 128x128 tile
   double per128_chain = 1.5;  // 32x64 one-shot tile: one dependent MFMA chain per wave
   double kmat = 9.0;  // one 128x64 kernel-matrix tile (fp64 exp/sqrt bound: 36 us for the 1056 tiles of n=4096 on 256 CUs)
 };
@@ -131,6 +132,7 @@ class DagBuilder {
   int crit_rows_ = 1;
   int rl_group_ = 32, rl_near_ = 1;
   bool rl_lauum_split_ = true;
+  bool big128_ = false;      // 128x128 tiles for the deep products without beta = 1
   bool rl_prog_ = false;     // right-looking plan: row-progressive inverse and K^-1 (rl_progressive)
   int prog_unear_ = -1, prog_knear_ = -1;  // single rows at the end of the U / K^-1 range lists (-1: rl_near_)
   int prog_ratio_ = 0;       // 0: rl_groups' ranges (aligned powers of two); >= 2: ranges growing by this factor from the end
@@ -206,6 +208,22 @@ class DagBuilder {
                 tiles.push_back({DAG_GEMM_64x64, bi, bj, ti * 64, tj * 64, ka * 64, kb * 64});
               }
             }
+          } else if (big128_ && !(op.flags & (DAGF_ACC | DAGF_CINIT))) {
+            // one 128x128 tile for both column halves: the union of their contraction ranges (the extra range of one half meets
+            // the zeros of a triangular operand, as for the two row halves)
+            if (hj == 0) {
+              int ka0, kb0, ka1, kb1;
+              krange(2 * bi + 1, 2 * bi, &ka0, &kb0);
+              const int tj_keep = tj;
+              (void)tj_keep;
+              // second half: the same formulas with tj + 1
+              ka1 = 2 * op.k0; kb1 = 2 * op.k1;
+              if (op.klim == 1) kb1 = std::min(kb1, tj + 2);
+              if (op.klim == 2) ka1 = std::max(ka1, tj + 1);
+              if (op.klim == 3) kb1 = std::min(kb1, 2 * bi + 2);
+              if (op.klim == 4) ka1 = std::max(ka1, 2 * bi);
+              tiles.push_back({DAG_GEMM_128x128, bi, bj, bi * 128, tj * 64, std::min(ka0, ka1) * 64, std::max(kb0, kb1) * 64});
+            }
           } else {
             int ka, kb;
             krange(2 * bi + 1, 2 * bi, &ka, &kb);  // klim 3: the tile's lower 64 rows decide, klim 4: its upper 64 rows; the extra range of the other half meets zeros
@@ -226,7 +244,8 @@ class DagBuilder {
         }
       }
       std::stable_sort(tiles.begin() + row_begin, tiles.end(), [](const Tile& a, const Tile& b) {
-        const long wa = (long)(a.kb - a.ka) * (a.kind == DAG_GEMM_128x64 ? 2 : 1), wb = (long)(b.kb - b.ka) * (b.kind == DAG_GEMM_128x64 ? 2 : 1);
+        auto wt = [](int kind) { return kind == DAG_GEMM_128x128 ? 4 : (kind == DAG_GEMM_128x64 ? 2 : 1); };
+        const long wa = (long)(a.kb - a.ka) * wt(a.kind), wb = (long)(b.kb - b.ka) * wt(b.kind);
         return wa > wb;
       });
     }
@@ -239,7 +258,7 @@ class DagBuilder {
     t.row0 = tl.row0; t.col0 = tl.col0;
     t.kbeg = tl.ka / bk_ * bk_;
     t.kend = (tl.kb + bk_ - 1) / bk_ * bk_;
-    *cost_us = cost_.overhead + (t.kend - t.kbeg) / 128.0 * (tl.kind == DAG_GEMM_128x64 ? cost_.per128_big : (tl.kind == DAG_GEMM_32x64 ? cost_.per128_chain : cost_.per128_small));
+    *cost_us = cost_.overhead + (t.kend - t.kbeg) / 128.0 * (tl.kind == DAG_GEMM_128x128 ? cost_.per128_big128 : (tl.kind == DAG_GEMM_128x64 ? cost_.per128_big : (tl.kind == DAG_GEMM_32x64 ? cost_.per128_chain : cost_.per128_small)));
     return t;
   }
   static int count_row(const std::vector<Tile>& tiles, int bi) {
@@ -857,6 +876,7 @@ class DagBuilder {
 
  public:
   void set_chain_bias(double us) { chain_bias_us_ = us; }
+  void set_big128(bool on) { big128_ = on; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -897,6 +917,10 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     // beta = 1, alpha = +1 and a non-empty contraction range (an empty one would store zeros over the first part's sums on the
     // 128x64 path, dag_gemm_tile); f32 problems never split (an f32 partial sum would be rounded on its way through memory):
     // build_lauum splits at the f64 stage depth only.
+    if (t.kind == DAG_GEMM_128x128 && (t.flags & (DAGF_ACC | DAGF_CINIT))) {
+      snprintf(buf, sizeof buf, "task %d: the 128x128 tile has no beta = 1 form (flags %x)", i, t.flags);
+      return buf;
+    }
     if (t.kind == DAG_GEMM_32x64 && (t.flags & (DAGF_AKM | DAGF_BKM | DAGF_CINIT | DAGF_CKINV))) {
       snprintf(buf, sizeof buf, "task %d: the 32x64 one-shot tile reads both operands [outer][k] and writes W1/W2/W3 (flags %x)", i, t.flags);
       return buf;
@@ -960,7 +984,7 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     } else if (t.kind == DAG_LML_FINAL) {
       for (int b = 0; b < (nblocks_total * 128 + 255) / 256; ++b) cell(5, b, 0, false);
     } else {
-      const int ta = t.kind == DAG_GEMM_128x64 ? 128 : (t.kind == DAG_GEMM_32x64 ? 32 : 64), tb = 64;
+      const int ta = (t.kind == DAG_GEMM_128x64 || t.kind == DAG_GEMM_128x128) ? 128 : (t.kind == DAG_GEMM_32x64 ? 32 : 64), tb = t.kind == DAG_GEMM_128x128 ? 128 : 64;
       const int ab = (t.flags & DAGF_A3) ? 7 : ((t.flags & DAGF_ABUF) ? 1 : 0), bb = (t.flags & DAGF_B3) ? 7 : ((t.flags & DAGF_BBUF) ? 1 : 0);
       const int cb = (t.flags & DAGF_CKINV) ? 6 : ((t.flags & DAGF_C3) ? 7 : ((t.flags & DAGF_CBUF) ? 1 : 0));
       if (t.kend <= t.kbeg) return "empty contraction range";

@@ -98,6 +98,9 @@ enum : uint16_t {
   // A(k+1,k) X_kk^T and A(k+1,k+1) -= L(k+1,k) L(k+1,k)^T), where a tile's latency counts and its throughput does not.
   // Same accumulation order per element as the other tiles (k ascending in MFMA steps of four): same bits.
   DAG_GEMM_32x64 = 8,
+  // 128x128 output tile for deep products without beta = 1 (no room in the LDS for the old values beside the stage buffers): half
+  // the tasks, 8 MFMAs per 6 fragment reads instead of 4 per 4.  Same accumulation order per element: same bits.
+  DAG_GEMM_128x128 = 9,
 };
 enum : uint16_t {
   DAGF_ABUF = 1,   // operand A lives in W2 (else W1)

@@ -602,9 +602,9 @@ struct Problem : ProblemBase {
       // 9.9 ms recursion / right-looking, 12288: 31.4 / 32.0, 16384: 72.3 / 75.5).
       dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
       static std::mutex cache_mu;
-      static std::map<std::array<int, 19>, std::shared_ptr<const DagPlan>> cache;
+      static std::map<std::array<int, 20>, std::shared_ptr<const DagPlan>> cache;
       auto plan_for = [&](int nwg) {
-        std::array<int, 19> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
+        std::array<int, 20> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
                                    env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                    env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1),
                                    env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0),
@@ -617,7 +617,15 @@ struct Problem : ProblemBase {
                                    // `extend` repeats a fit's evaluation bit for bit.
                                    env_int("HBEGP_DAG_PROG", np / NB <= DAG_PROG_MAX_BLOCKS ? 1 : 0),
                                    env_int("HBEGP_DAG_PROG_UNEAR", -1), env_int("HBEGP_DAG_PROG_KNEAR", -1), env_int("HBEGP_DAG_PROG_SMALL", 0),
-                                   env_int("HBEGP_DAG_PROG_RATIO", 0), env_int("HBEGP_DAG_CHAIN_BIAS", 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
+                                   env_int("HBEGP_DAG_PROG_RATIO", 0), env_int("HBEGP_DAG_CHAIN_BIAS", 0),
+                                   // 128x128 tiles for the deep products without beta = 1 when several slots share the chip (throughput: half the
+                                   // tasks, fewer fragment reads per MFMA): three-run fits M f64 1.727 -> 1.740, M f32 2.64 -> 2.77, C4 0.233 ->
+                                   // 0.245; one evaluation alone gets SLOWER (fewer, longer tasks on 256 workgroups: n=4096 2.08 -> 2.22 ms), so
+                                   // single-slot problems keep 128x64.  The bits do not depend on the tile shape (one k-ascending chain of MFMA
+                                   // accumulations per element), so `extend` still repeats a fit's evaluation bit for bit.
+                                   // Below 32 blocks the fits lose (n=1536 10.4 -> 8.5, 2048 7.0 -> 6.4, 3072 3.36 -> 3.13 fits/s: too few deep
+                                   // products, the longer tasks only unbalance the end of the launch).
+                                   env_int("HBEGP_DAG_BIG128", (n_slots >= 2 && np / NB >= 32) ? 1 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
         std::shared_ptr<const DagPlan> cached;
         {
           std::lock_guard<std::mutex> lk(cache_mu);
@@ -629,6 +637,7 @@ struct Problem : ProblemBase {
           builder.set_rl(key[9], key[10], key[11] != 0, key[12] != 0);
           builder.set_rl_progressive(key[13] != 0, key[14], key[15], key[16] != 0, key[17]);
           builder.set_chain_bias((double)key[18]);
+          builder.set_big128(key[19] != 0);
           cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_, dag_lauum_, dag_rl_));
           std::lock_guard<std::mutex> lk(cache_mu);
           if (cache.size() > 64) cache.clear();
@@ -2319,6 +2328,7 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   DagBuilder builder(bk, small_h, nwg, (fine & 1) != 0);
   builder.set_rl_progressive((fine & 16) != 0, -1, -1, false, getenv("HBEGP_DAG_PROG_RATIO") ? atoi(getenv("HBEGP_DAG_PROG_RATIO")) : 0);
   builder.set_chain_bias(getenv("HBEGP_DAG_CHAIN_BIAS") ? atof(getenv("HBEGP_DAG_CHAIN_BIAS")) : 0.0);
+  builder.set_big128(getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) != 0);
   // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too; bit 2: the K^-1 = X^T X tiles behind the recursion;
   // bit 3: the right-looking plan; bit 4: its row-progressive inverse and K^-1
   DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0, (fine & 4) != 0, (fine & 8) != 0);

@@ -271,12 +271,14 @@ def test_incremental_extend_falls_back_when_the_prefix_differs():
 
 @pytest.mark.parametrize("n_restarts", [2, 0])
 @pytest.mark.parametrize("n,dtype", [(100, np.float64), (500, np.float64), (600, np.float32), (700, np.float64), (1100, np.float64), (1300, np.float32), (2700, np.float64),
-                                     (2700, np.float32)])
+                                     (2700, np.float32), (4000, np.float64)])
 def test_extend_repeats_the_fits_own_evaluation_bit_for_bit(n, dtype, n_restarts):
     # One order of operations for one theta: `extend` at the fitted theta runs the evaluation the way the
     # fit ran it (one launch in the LDS up to 128 rows -- inside the persistent fit kernel or alone --, launches below 6 blocks,
     # the task queue from there on: row-progressive plan up to 20 blocks, divide-and-conquer inverse above, whose single-slot K^-1
-    # split continues the undivided tiles' accumulation), so lml, alpha and K^-1 are the captured evaluation's, bit for bit.
+    # split continues the undivided tiles' accumulation; from 32 blocks on a fit with several runs uses 128x128 tiles for the deep
+    # products and `extend` 128x64 ones: one k-ascending chain of MFMA accumulations per element either way), so lml, alpha and K^-1
+    # are the captured evaluation's, bit for bit.
     # n_restarts = 0: a fit with ONE slot per device (it used to pick its path with the single-evaluation threshold of
     # 16 blocks while extend used the fit's 8 -- different orders of operations for n = 1024..1920); the path is now a function of
     # n alone.

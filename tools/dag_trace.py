@@ -10,9 +10,9 @@ t0 = a[:, 6].min()
 pulled, ready, comp, pub = [(a[:, c] - t0) * 0.01 for c in (6, 7, 8, 9)]  # microseconds
 kind, depth, nwait = a[:, 1], a[:, 4], a[:, 5]
 print(f"tasks {len(a)}  makespan {pub.max():.1f} us  CUs used {len(set(zip(a[:,10], a[:,11] & 0xffffff00)))}")
-names = {0: "gemm128x64", 1: "gemm64x64", 2: "leaf", 8: "gemm32x64"}
+names = {0: "gemm128x64", 1: "gemm64x64", 2: "leaf", 8: "gemm32x64", 9: "gemm128x128"}
 print(f"{'class':24s} {'n':>5s} {'compute':>9s} {'publish':>9s} {'wait':>9s} {'total busy us':>14s}")
-for k in (2, 8, 1, 0):
+for k in (2, 8, 1, 0, 9):
     for d in sorted(set(depth[kind == k])):
         m = (kind == k) & (depth == d)
         c, p, w = comp[m] - ready[m], pub[m] - comp[m], ready[m] - pulled[m]
@@ -20,10 +20,10 @@ for k in (2, 8, 1, 0):
 # where the busy time exceeds the MFMA-only ideal (one CU: 128 fp64 flop per clock at 2.4 GHz = 0.307 TFLOP/s), by class
 ideal_all, busy_all = 0.0, 0.0
 rows = []
-for k in (8, 1, 0):
+for k in (8, 1, 0, 9):
     for d in sorted(set(depth[kind == k])):
         m = (kind == k) & (depth == d)
-        flop = {0: 128, 1: 64, 8: 32}[k] * 64 * d * 2.0
+        flop = {0: 128 * 64, 1: 64 * 64, 8: 32 * 64, 9: 128 * 128}[k] * d * 2.0
         ideal = flop / 0.3072e6  # us
         b = (pub[m] - ready[m])
         rows.append((b.sum() - ideal * m.sum(), names[k], d, int(m.sum()), ideal, float(np.median(b))))
