@@ -142,3 +142,28 @@ def test_plan_builder_and_optimiser_are_clean_under_sanitizers(tmp_path):
                            "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tools", "san_plan.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "0 problems" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("nb", [2, 3, 5, 8, 16, 24, 32, 33, 48])
+def test_plans_with_128x128_tiles_are_sound(nb, monkeypatch):
+    # HBEGP_DAG_BIG128: the deep products without beta = 1 as 128x128 tiles (round 4; the default for multi-slot problems from 32
+    # blocks on): fewer tasks, the same flops, sound in every plan -- and never a beta = 1 task of that kind (the checker rejects one)
+    _, base = plan(nb, 16, 4, 96, 1 | 4 | 8)
+    monkeypatch.setenv("HBEGP_DAG_BIG128", "1")
+    for bk in (16, 32):
+        for small_h, nwg, fine in [(4, 96, 1 | 4 | 8), (4, 256, 1 | 4 | 8 | 16), (8, 85, 1 | 4), (0, 3, 1 | 4 | 8)]:
+            rc, info = plan(nb, bk, small_h, nwg, fine)
+            assert rc == 0, (nb, bk, small_h, nwg, fine, info["err"])
+            assert info["gflop"] == pytest.approx(base["gflop"], rel=1e-12)
+    if nb >= 8:
+        _, big = plan(nb, 16, 4, 96, 1 | 4 | 8)
+        assert big["ntasks"] < base["ntasks"]
+
+
+def test_chain_bias_keeps_the_queue_topological(monkeypatch):
+    # HBEGP_DAG_CHAIN_BIAS moves the chain's tasks forward in the queue, never in front of a task they depend on
+    for bias in ("5", "20", "200"):
+        monkeypatch.setenv("HBEGP_DAG_CHAIN_BIAS", bias)
+        for nb, fine in ((16, 1 | 4 | 8 | 16), (32, 1 | 4 | 8), (9, 1 | 4 | 8)):
+            rc, info = plan(nb, 16, 4, 96, fine)
+            assert rc == 0, (bias, nb, info["err"])
