@@ -121,8 +121,11 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   // there; the loads' latency hides under the contraction -- it was a third of a 128-deep update's time)
   // The 64x64 tile keeps them in registers (8); the 128x64 tile (16: the kernel's diagonal block would spill) parks them in
   // the LDS behind the stage buffers until the epilogue.  Measured on the 128-deep 128x64 update: 13.8 -> 9.9 us.
-  constexpr bool NOACC = TB == 128;  // the 128x128 tile: alpha * A B only (the plan never gives it beta = 1; dag_plan_validate checks)
-  const bool accum = !NOACC && (flags & DAGF_ACC) != 0;
+  // the 128x128 tile has no room in the LDS for the old values beside the stage buffers: with beta = 1 it fetches them in the
+  // epilogue (their latency is exposed once per task -- a task that replaces two); it never continues a sum (no DAGF_CINIT:
+  // dag_plan_validate checks)
+  constexpr bool NOACC = TB == 128;
+  const bool accum = (flags & DAGF_ACC) != 0;
   const bool cinit = !NOACC && sizeof(T) == 8 && (flags & DAGF_CINIT) != 0;  // the old values start the accumulation (engine.hpp)
   constexpr bool PREFETCH_C = TA == 64 || (sizeof(T) == 8 && DAG_F64_KMUL > 1);
   constexpr int STASH_OFF = 2 * (G::LDSA + G::LDSB);  // in elements of T, behind [A buf0 | A buf1 | B buf0 | B buf1]
@@ -294,6 +297,17 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   // epilogue: write-through stores (read by other workgroups of this launch)
   const int er0 = row0 + wm * (TA / G::WM), ec0 = col0 + wn * (TB / G::WN) + (lane & 15);
   const bool neg = (flags & DAGF_NEG) != 0;
+  T cend[NOACC ? TMA : 1][NOACC ? TMB : 1][4];
+  if constexpr (NOACC) {
+    if (accum) {  // uniform: all the loads first, one latency
+#pragma unroll
+      for (int a = 0; a < TMA; ++a)
+#pragma unroll
+        for (int b = 0; b < TMB; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cend[a][b][r] = Cg[(size_t)(er0 + a * 16 + C::crow(lane, r)) * ld + ec0 + b * 16];
+    }
+  }
 #pragma unroll
   for (int a = 0; a < TMA; ++a)
 #pragma unroll
@@ -310,6 +324,8 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
           if (accum && !cinit) v += cold[a][b][r];
         } else if constexpr (!NOACC) {
           if (accum && !cinit) v += lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t];
+        } else {
+          if (accum) v += cend[a][b][r];
         }
         gstore<true>(p, v);
       }

@@ -132,7 +132,8 @@ class DagBuilder {
   int crit_rows_ = 1;
   int rl_group_ = 32, rl_near_ = 1;
   bool rl_lauum_split_ = true;
-  bool big128_ = false;      // 128x128 tiles for the deep products without beta = 1
+  bool big128_ = false;      // 128x128 tiles for the bulk products (never for a continued sum)
+  bool big128_acc_ = false;  // ... also with beta = 1 (the old values fetched in the epilogue)
   bool rl_prog_ = false;     // right-looking plan: row-progressive inverse and K^-1 (rl_progressive)
   int prog_unear_ = -1, prog_knear_ = -1;  // single rows at the end of the U / K^-1 range lists (-1: rl_near_)
   int prog_ratio_ = 0;       // 0: rl_groups' ranges (aligned powers of two); >= 2: ranges growing by this factor from the end
@@ -208,7 +209,7 @@ class DagBuilder {
                 tiles.push_back({DAG_GEMM_64x64, bi, bj, ti * 64, tj * 64, ka * 64, kb * 64});
               }
             }
-          } else if (big128_ && !(op.flags & (DAGF_ACC | DAGF_CINIT))) {
+          } else if (big128_ && !(op.flags & DAGF_CINIT) && (big128_acc_ || !(op.flags & DAGF_ACC))) {
             // one 128x128 tile for both column halves: the union of their contraction ranges (the extra range of one half meets
             // the zeros of a triangular operand, as for the two row halves)
             if (hj == 0) {
@@ -876,7 +877,7 @@ class DagBuilder {
 
  public:
   void set_chain_bias(double us) { chain_bias_us_ = us; }
-  void set_big128(bool on) { big128_ = on; }
+  void set_big128(bool on, bool with_acc = false) { big128_ = on; big128_acc_ = on && with_acc; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -917,8 +918,8 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
     // beta = 1, alpha = +1 and a non-empty contraction range (an empty one would store zeros over the first part's sums on the
     // 128x64 path, dag_gemm_tile); f32 problems never split (an f32 partial sum would be rounded on its way through memory):
     // build_lauum splits at the f64 stage depth only.
-    if (t.kind == DAG_GEMM_128x128 && (t.flags & (DAGF_ACC | DAGF_CINIT))) {
-      snprintf(buf, sizeof buf, "task %d: the 128x128 tile has no beta = 1 form (flags %x)", i, t.flags);
+    if (t.kind == DAG_GEMM_128x128 && (t.flags & DAGF_CINIT)) {
+      snprintf(buf, sizeof buf, "task %d: the 128x128 tile cannot continue a sum (flags %x)", i, t.flags);
       return buf;
     }
     if (t.kind == DAG_GEMM_32x64 && (t.flags & (DAGF_AKM | DAGF_BKM | DAGF_CINIT | DAGF_CKINV))) {

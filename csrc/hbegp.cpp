@@ -625,7 +625,10 @@ struct Problem : ProblemBase {
                                    // accumulations per element), so `extend` still repeats a fit's evaluation bit for bit.
                                    // Below 32 blocks the fits lose (n=1536 10.4 -> 8.5, 2048 7.0 -> 6.4, 3072 3.36 -> 3.13 fits/s: too few deep
                                    // products, the longer tasks only unbalance the end of the launch).
-                                   env_int("HBEGP_DAG_BIG128", (n_slots >= 2 && np / NB >= 32) ? 1 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
+                                   // 2: also the tiles with beta = 1 (the trailing updates; the old values are then fetched in the epilogue): M f64
+                                   // 1.711 / 1.737 / 1.739 -> 1.753 / 1.754 / 1.756 (alternating), M f32 2.76 -> 2.80, C4 0.242 -> 0.249 fits/s.
+                                   // One evaluation alone: n=6144 4.58 -> 4.73 ms (worse), n=8192 9.69 -> 9.31 ms: from 64 blocks on there too.
+                                   env_int("HBEGP_DAG_BIG128", ((n_slots >= 2 && np / NB >= 32) || np / NB >= 64) ? 2 : 0)};  // one evaluation alone: 2.21 -> 2.17 ms at n=4096, 1.02 -> 0.97 at 2048; a fit: 1.67 -> 1.66
         std::shared_ptr<const DagPlan> cached;
         {
           std::lock_guard<std::mutex> lk(cache_mu);
@@ -637,7 +640,7 @@ struct Problem : ProblemBase {
           builder.set_rl(key[9], key[10], key[11] != 0, key[12] != 0);
           builder.set_rl_progressive(key[13] != 0, key[14], key[15], key[16] != 0, key[17]);
           builder.set_chain_bias((double)key[18]);
-          builder.set_big128(key[19] != 0);
+          builder.set_big128(key[19] != 0, key[19] >= 2);
           cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_, dag_lauum_, dag_rl_));
           std::lock_guard<std::mutex> lk(cache_mu);
           if (cache.size() > 64) cache.clear();
@@ -2328,7 +2331,7 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   DagBuilder builder(bk, small_h, nwg, (fine & 1) != 0);
   builder.set_rl_progressive((fine & 16) != 0, -1, -1, false, getenv("HBEGP_DAG_PROG_RATIO") ? atoi(getenv("HBEGP_DAG_PROG_RATIO")) : 0);
   builder.set_chain_bias(getenv("HBEGP_DAG_CHAIN_BIAS") ? atof(getenv("HBEGP_DAG_CHAIN_BIAS")) : 0.0);
-  builder.set_big128(getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) != 0);
+  builder.set_big128(getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) != 0, getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) >= 2);
   // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too; bit 2: the K^-1 = X^T X tiles behind the recursion;
   // bit 3: the right-looking plan; bit 4: its row-progressive inverse and K^-1
   DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0, (fine & 4) != 0, (fine & 8) != 0);
