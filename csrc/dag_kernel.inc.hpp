@@ -32,6 +32,20 @@
 #ifndef DAG_F64_KMUL
 #define DAG_F64_KMUL 1
 #endif
+// Stage-loop form per tile shape (dag_gemm_tile): 0 = round 2-4 (a stage's fragments in registers, reads / loads / stores in
+// clumps), 1 = round 5 (one k-step's fragments double-buffered, every non-MFMA instruction in the shadow of an MFMA).
+#ifndef DAG_PIPE_128x128
+#define DAG_PIPE_128x128 0
+#endif
+#ifndef DAG_PIPE_F32_128x128
+#define DAG_PIPE_F32_128x128 0  /* f32: form 0 keeps 48 fragment registers beside the fp64 chunk totals and spills (round 4: 4 VGPRs, 32 B scratch) */
+#endif
+#ifndef DAG_PIPE_128x64
+#define DAG_PIPE_128x64 0
+#endif
+#ifndef DAG_PIPE_64x64
+#define DAG_PIPE_64x64 0
+#endif
 template <typename T, int TA, int TB>
 struct DagGeom {
   using C = Cfg<T>;
@@ -57,7 +71,7 @@ static_assert(DAG_LDS_BYTES <= 163840, "the diagonal block and the control words
 // free (claiming it a whole task earlier parks the chain's tasks behind bulk tiles: measured 2.05 -> 3.06 ms per evaluation).
 // -DDAG_STAMP_INNER (diagnostic build, tools/trace_inner.py): two more time stamps per tile task -- first stage in the LDS (the
 // first MFMA can start) and last MFMA issued -- packed into the trace's CU-id word (low 32 bits of the 100 MHz clock each).
-template <typename T, int TA, int TB, typename PullFn, typename FetchFn>
+template <typename T, int TA, int TB, int PIPE, typename PullFn, typename FetchFn>
 __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int kbeg, int kend, T* __restrict__ W1,
                                               T* __restrict__ W2, T* __restrict__ W3, T* __restrict__ Kinv, int ld, char* smem_raw,
                                               PullFn pull, FetchFn fetch, unsigned long long* inner = nullptr) {
@@ -97,6 +111,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   const size_t a_qs = (size_t)a_rpp * ld, b_qs = (size_t)b_rpp * ld;
 
   vec_t ra0[NCHA], rb0[NCHB], ra1[NCHA], rb1[NCHB];
+  vec_t ra2[(PIPE & 15) == 2 ? NCHA : 1], rb2[(PIPE & 15) == 2 ? NCHB : 1];  // PIPE 2: a third set, loads three stages ahead
   auto load_stage = [&](vec_t (&ra)[NCHA], vec_t (&rb)[NCHB]) {
 #pragma unroll
     for (int q = 0; q < NCHA; ++q) ra[q] = *reinterpret_cast<const vec_t*>(pA + q * a_qs);
@@ -175,6 +190,9 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 #pragma unroll
           for (int r = 0; r < 4; ++r) tot[a][b][r] += (double)acc[a][b][r];
           acc[a][b] = acc_t{0, 0, 0, 0};
+          // one 16x16 block at a time: left to itself the scheduler converts many blocks ahead of their additions, and the
+          // 128x128 tile (64 total registers) then no longer fits beside the kernel's own live values (round 4: 4 spilled VGPRs)
+          if constexpr (TA * TB >= 128 * 128) __builtin_amdgcn_sched_barrier(0);
         }
     }
   };
@@ -184,113 +202,317 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   const int fa0 = (wm * (TA / G::WM) + (lane & 15)) * soA + (lane >> 4) * skA;
   const int fb0 = 2 * G::LDSA + (wn * (TB / G::WN) + (lane & 15)) * soB + (lane >> 4) * skB;
 
-  // Same software pipeline as gemm_kernel's 64-tile: global loads two stages ahead in two register sets, LDS double
-  // buffer, the fragments of a whole stage in registers, the next stage's first fragments read under the MFMAs of the
-  // last k-step.
   constexpr int NK = BK / 4;
-  T fa[NK][TMA], fb[NK][TMB];
-  auto read_frags = [&](int buf, int k4) {
-    const int ia = buf * G::LDSA + fa0 + k4 * 4 * skA, ib = buf * G::LDSB + fb0 + k4 * 4 * skB;
+  if constexpr (PIPE == 0) {
+    // Same software pipeline as gemm_kernel's 64-tile: global loads two stages ahead in two register sets, LDS double
+    // buffer, the fragments of a whole stage in registers, the next stage's first fragments read under the MFMAs of the
+    // last k-step.
+    T fa[NK][TMA], fb[NK][TMB];
+    auto read_frags = [&](int buf, int k4) {
+      const int ia = buf * G::LDSA + fa0 + k4 * 4 * skA, ib = buf * G::LDSB + fb0 + k4 * 4 * skB;
 #pragma unroll
-    for (int a = 0; a < TMA; ++a) fa[k4][a] = lds[ia + a * 16 * soA];
+      for (int a = 0; a < TMA; ++a) fa[k4][a] = lds[ia + a * 16 * soA];
 #pragma unroll
-    for (int b2 = 0; b2 < TMB; ++b2) fb[k4][b2] = lds[ib + b2 * 16 * soB];
-  };
-  auto mfma_step = [&](int k4) {
+      for (int b2 = 0; b2 < TMB; ++b2) fb[k4][b2] = lds[ib + b2 * 16 * soB];
+    };
+    auto mfma_step = [&](int k4) {
 #pragma unroll
-    for (int a = 0; a < TMA; ++a)
+      for (int a = 0; a < TMA; ++a)
 #pragma unroll
-      for (int b2 = 0; b2 < TMB; ++b2) acc[a][b2] = C::mfma(fa[k4][a], fb[k4][b2], acc[a][b2]);
-  };
-  auto stage = [&](int cur, bool do_load, vec_t (&la)[NCHA], vec_t (&lb)[NCHB], bool do_store, vec_t (&sa)[NCHA],
-                   vec_t (&sb)[NCHB], bool has_next) {
-    if (do_load) load_stage(la, lb);
+        for (int b2 = 0; b2 < TMB; ++b2) acc[a][b2] = C::mfma(fa[k4][a], fb[k4][b2], acc[a][b2]);
+    };
+    auto stage = [&](int cur, bool do_load, vec_t (&la)[NCHA], vec_t (&lb)[NCHB], bool do_store, vec_t (&sa)[NCHA],
+                     vec_t (&sb)[NCHB], bool has_next) {
+      if (do_load) load_stage(la, lb);
+      // f32 128x128 (NK = 8: 48 fragment registers beside 64 fp64 chunk totals): the fragments of a stage are read in two
+      // halves, the second under the first half's MFMAs -- with all of them up front the kernel spilled (round 4: 4 VGPRs)
+      constexpr bool SPLIT_READS = NK >= 8 && TA * TB >= 128 * 128;
+      constexpr int KH = SPLIT_READS ? NK / 2 : NK - 1;  // last k-step read up front
 #pragma unroll
-    for (int k4 = 1; k4 < NK; ++k4) read_frags(cur, k4);
+      for (int k4 = 1; k4 <= KH; ++k4) read_frags(cur, k4);
+      if constexpr (SPLIT_READS) {
 #pragma unroll
-    for (int k4 = 0; k4 + 2 < NK; ++k4) mfma_step(k4);
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_store) store_stage(cur ^ 1, sa, sb);
-    if (NK >= 2) mfma_step(NK - 2);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    if (has_next) read_frags(cur ^ 1, 0);
-    mfma_step(NK - 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, TMA + TMB, 0);  // reads first: their latency hides under the MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x008, TMA * TMB, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    kabs += BK;
-    if (CHUNKED && kabs % F32_CHUNK == 0) flush();
-  };
-  if (nstages > 0) {
-    load_stage(ra0, rb0);
-    if (nstages > 1) load_stage(ra1, rb1);
-    if constexpr (!PREFETCH_C && !NOACC) {
-      if (accum) {  // old values of the output tile -> LDS stash (each thread its own 16 slots, lane-contiguous)
-        T cst[TMA][TMB][4];
-        const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
+        for (int k4 = 0; k4 + 1 < KH; ++k4) mfma_step(k4);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < TMA; ++a)
+        for (int k4 = KH + 1; k4 < NK; ++k4) read_frags(cur, k4);
 #pragma unroll
-          for (int b = 0; b < TMB; ++b)
+        for (int k4 = KH - 1; k4 + 2 < NK; ++k4) mfma_step(k4);
+      } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) cst[a][b][r] = Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16];
-        store_stage(0, ra0, rb0);
-        bool stash = true;
-        if constexpr (sizeof(T) == 8) {
-          if (cinit) {
-            stash = false;
-#pragma unroll
-            for (int a = 0; a < TMA; ++a)
-#pragma unroll
-              for (int b = 0; b < TMB; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[a][b][r] = cst[a][b][r];
-          }
-        }
-        if (stash) {
+        for (int k4 = 0; k4 + 2 < NK; ++k4) mfma_step(k4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_store) store_stage(cur ^ 1, sa, sb);
+      if (NK >= 2) mfma_step(NK - 2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) read_frags(cur ^ 1, 0);
+      mfma_step(NK - 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, TMA + TMB, 0);  // reads first: their latency hides under the MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, TMA * TMB, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      kabs += BK;
+      if (CHUNKED && kabs % F32_CHUNK == 0) flush();
+    };
+    if (nstages > 0) {
+      load_stage(ra0, rb0);
+      if (nstages > 1) load_stage(ra1, rb1);
+      if constexpr (!PREFETCH_C && !NOACC) {
+        if (accum) {  // old values of the output tile -> LDS stash (each thread its own 16 slots, lane-contiguous)
+          T cst[TMA][TMB][4];
+          const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
 #pragma unroll
           for (int a = 0; a < TMA; ++a)
 #pragma unroll
             for (int b = 0; b < TMB; ++b)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t] = cst[a][b][r];
+              for (int r = 0; r < 4; ++r) cst[a][b][r] = Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16];
+          store_stage(0, ra0, rb0);
+          bool stash = true;
+          if constexpr (sizeof(T) == 8) {
+            if (cinit) {
+              stash = false;
+#pragma unroll
+              for (int a = 0; a < TMA; ++a)
+#pragma unroll
+                for (int b = 0; b < TMB; ++b)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) acc[a][b][r] = cst[a][b][r];
+            }
+          }
+          if (stash) {
+#pragma unroll
+            for (int a = 0; a < TMA; ++a)
+#pragma unroll
+              for (int b = 0; b < TMB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t] = cst[a][b][r];
+          }
+        } else {
+          store_stage(0, ra0, rb0);
         }
       } else {
         store_stage(0, ra0, rb0);
       }
+      __syncthreads();
+      read_frags(0, 0);
+  #ifdef DAG_STAMP_INNER
+      unsigned long long st1 = 0;
+      if (inner && t == 0) st1 = __builtin_amdgcn_s_memrealtime();
+  #endif
+      int s = 0;
+      for (; s + 3 < nstages; s += 2) {
+        stage(0, true, ra0, rb0, true, ra1, rb1, true);
+        stage(1, true, ra1, rb1, true, ra0, rb0, true);
+      }
+      const int left = nstages - s;  // 1..3
+      if (left <= 2) pull();
+      if (left == 1) fetch();
+      stage(0, left > 2, ra0, rb0, left > 1, ra1, rb1, left > 1);
+      if (left > 2) pull();
+      if (left == 2) fetch();
+      if (left > 1) stage(1, false, ra1, rb1, left > 2, ra0, rb0, left > 2);
+      if (left > 2) {
+        fetch();
+        stage(0, false, ra0, rb0, false, ra1, rb1, false);
+      }
+  #ifdef DAG_STAMP_INNER
+      if (inner && t == 0) *inner = ((st1 & 0xffffffffull) << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
+  #endif
     } else {
-      store_stage(0, ra0, rb0);
-    }
-    __syncthreads();
-    read_frags(0, 0);
-#ifdef DAG_STAMP_INNER
-    unsigned long long st1 = 0;
-    if (inner && t == 0) st1 = __builtin_amdgcn_s_memrealtime();
-#endif
-    int s = 0;
-    for (; s + 3 < nstages; s += 2) {
-      stage(0, true, ra0, rb0, true, ra1, rb1, true);
-      stage(1, true, ra1, rb1, true, ra0, rb0, true);
-    }
-    const int left = nstages - s;  // 1..3
-    if (left <= 2) pull();
-    if (left == 1) fetch();
-    stage(0, left > 2, ra0, rb0, left > 1, ra1, rb1, left > 1);
-    if (left > 2) pull();
-    if (left == 2) fetch();
-    if (left > 1) stage(1, false, ra1, rb1, left > 2, ra0, rb0, left > 2);
-    if (left > 2) {
+      pull();
       fetch();
-      stage(0, false, ra0, rb0, false, ra1, rb1, false);
     }
-#ifdef DAG_STAMP_INNER
-    if (inner && t == 0) *inner = ((st1 & 0xffffffffull) << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
-#endif
   } else {
-    pull();
-    fetch();
+    // PIPE 1 (round 5): the stage loop with every wave's LDS reads, global loads and LDS stores dealt one by one into the
+    // shadows of its own MFMAs.  Why: the two waves of a SIMD share one fp64 MFMA pipe and the pipe serves the older wave
+    // first, so the older wave runs ahead to the stage barrier and the younger one then runs most of its stage ALONE -- and
+    // whenever a lone wave issues a clump of non-MFMA instructions (PIPE 0: 18 fragment reads + 4 global loads at the head of a
+    // stage, 4 LDS stores in the middle) the pipe idles: the stage loop ran at 92 % of the MFMA rate.  Here the fragments of
+    // ONE k-step are double-buffered (k-step k lives in set k & 1: 2 x (TMA + TMB) values instead of NK x), each MFMA is
+    // followed by at most one fragment read of the NEXT k-step and one load or store, and sched_group_barrier pins that
+    // order, so a wave alone keeps the pipe busy.  Same k-ascending chain of MFMA accumulations per element: same bits.
+    // An interval = what lies between two stage barriers: MFMAs of the last k-step of stage s-1 (fragments already in
+    // registers), then k-steps 0 .. NK-2 of stage s; the loads of stage s+2 sit in the first group, the LDS stores of stage s+1
+    // in the group before the last one.
+    static_assert(NK % 2 == 0 && NK >= 2, "k-step k lives in fragment set k & 1 across stage boundaries");
+    // tools/tile_ubench only (wrong results, timing only): PIPE = 1 + 16 * ABL switches parts of the loop off -- 1: no global
+    // loads, 2: no LDS stores, 4: no stage barrier, 8: no fragment reads (what is each worth beside the MFMAs?)
+    constexpr int ABL = PIPE >> 4;
+    constexpr int NF = TMA + TMB, NM = TMA * TMB;
+    constexpr int RPM = (NF + NM - 1) / NM;  // fragment reads dealt behind one MFMA
+    T fr[2][NF];
+    auto read_frag = [&](int set, int buf, int k4, int i) {
+      if (i < TMA) fr[set][i] = lds[buf * G::LDSA + fa0 + k4 * 4 * skA + i * 16 * soA];
+      else fr[set][i] = lds[buf * G::LDSB + fb0 + k4 * 4 * skB + (i - TMA) * 16 * soB];
+    };
+    // the MFMAs of one k-step (fragments in set ms) with the reads of k-step rk of buffer rbuf (into set ms ^ 1) in their shadows
+    auto group = [&](int ms, bool rd, int rbuf, int rk) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        acc[i / TMB][i % TMB] = C::mfma(fr[ms][i / TMB], fr[ms][TMA + i % TMB], acc[i / TMB][i % TMB]);
+        if (rd) {
+#pragma unroll
+          for (int q = 0; q < RPM; ++q)
+            if (i * RPM + q < NF) read_frag(ms ^ 1, rbuf, rk, i * RPM + q);
+        }
+      }
+    };
+    // pins the issue order of one group: MFMA, its fragment reads, then (first NV MFMAs) one global load / (first NW) one LDS store
+    auto pin = [&](bool rd, int nv, int nw) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (rd && i * RPM < NF) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+        if (i < nv) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (i < nw) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    };
+    constexpr int KST = NK >= 4 ? NK - 3 : 0;  // the k-step group that carries the LDS stores of the next stage
+    auto interval = [&](int cur, bool g0, bool do_load, vec_t (&la)[NCHA], vec_t (&lb)[NCHB], bool do_store, vec_t (&sa)[NCHA],
+                        vec_t (&sb)[NCHB]) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (g0) {
+        if (do_load && !(ABL & 1)) load_stage(la, lb);
+        group((NK - 1) & 1, !(ABL & 8), cur, 0);
+        pin(true, NCHA + NCHB, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        kabs += BK;
+        if (CHUNKED && kabs % F32_CHUNK == 0) flush();
+      } else {
+        if (do_load && !(ABL & 1)) load_stage(la, lb);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) read_frag(0, cur, 0, i);
+        if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i) read_frag(1, cur, 1, i);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k4 = 0; k4 + 1 < NK; ++k4) {
+        const bool st = do_store && k4 == KST && !(ABL & 2);
+        if (st) store_stage(cur ^ 1, sa, sb);
+        group(k4 & 1, !(ABL & 8), cur, k4 + 1);
+        pin(true, 0, k4 == KST ? NCHA + NCHB : 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!(ABL & 4)) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nstages > 0) {
+      load_stage(ra0, rb0);
+      if (nstages > 1) load_stage(ra1, rb1);
+      if constexpr ((PIPE & 15) == 2) {
+        if (nstages > 2) load_stage(ra2, rb2);
+      }
+      if constexpr (!PREFETCH_C && !NOACC) {
+        if (accum) {  // old values of the output tile -> LDS stash (as PIPE 0)
+          T cst[TMA][TMB][4];
+          const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
+#pragma unroll
+          for (int a = 0; a < TMA; ++a)
+#pragma unroll
+            for (int b = 0; b < TMB; ++b)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cst[a][b][r] = Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16];
+          store_stage(0, ra0, rb0);
+          bool stash = true;
+          if constexpr (sizeof(T) == 8) {
+            if (cinit) {
+              stash = false;
+#pragma unroll
+              for (int a = 0; a < TMA; ++a)
+#pragma unroll
+                for (int b = 0; b < TMB; ++b)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) acc[a][b][r] = cst[a][b][r];
+            }
+          }
+          if (stash) {
+#pragma unroll
+            for (int a = 0; a < TMA; ++a)
+#pragma unroll
+              for (int b = 0; b < TMB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t] = cst[a][b][r];
+          }
+        } else {
+          store_stage(0, ra0, rb0);
+        }
+      } else {
+        store_stage(0, ra0, rb0);
+      }
+      __syncthreads();
+#ifdef DAG_STAMP_INNER
+      unsigned long long st1 = 0;
+      if (inner && t == 0) st1 = __builtin_amdgcn_s_memrealtime();
+#endif
+      int s = 0;
+      bool g0 = false;
+      if constexpr ((PIPE & 15) == 2) {
+        // three register sets: stage s is loaded into set s % 3 three intervals before it is read, interval s stores stage s + 1
+        int cur = 0;
+        for (; s + 5 < nstages; s += 3) {
+          interval(cur, g0, true, ra0, rb0, true, ra1, rb1);
+          g0 = true;
+          interval(cur ^ 1, true, true, ra1, rb1, true, ra2, rb2);
+          interval(cur, true, true, ra2, rb2, true, ra0, rb0);
+          cur ^= 1;
+        }
+        const int left = nstages - s;  // 1..5; interval j of the tail: loads while j + 3 < left, stores while j + 1 < left
+        const int jp = left > 3 ? left - 3 : 0;  // first interval without a load: the next queue entry is claimed in front of it
+        if (jp == 0) pull();
+        if (left == 1) fetch();
+        interval(cur, g0, 3 < left, ra0, rb0, 1 < left, ra1, rb1);
+        if (left > 1) {
+          if (jp == 1) pull();
+          if (left == 2) fetch();
+          interval(cur ^ 1, true, 4 < left, ra1, rb1, 2 < left, ra2, rb2);
+        }
+        if (left > 2) {
+          if (jp == 2) pull();
+          if (left == 3) fetch();
+          interval(cur, true, false, ra2, rb2, 3 < left, ra0, rb0);
+        }
+        if (left > 3) {
+          if (left == 4) fetch();
+          interval(cur ^ 1, true, false, ra0, rb0, 4 < left, ra1, rb1);
+        }
+        if (left > 4) {
+          fetch();
+          interval(cur, true, false, ra1, rb1, false, ra2, rb2);
+        }
+      } else {
+        for (; s + 3 < nstages; s += 2) {
+          interval(0, g0, true, ra0, rb0, true, ra1, rb1);
+          g0 = true;
+          interval(1, true, true, ra1, rb1, true, ra0, rb0);
+        }
+        const int left = nstages - s;  // 1..3
+        if (left <= 2) pull();
+        if (left == 1) fetch();
+        interval(0, g0, left > 2, ra0, rb0, left > 1, ra1, rb1);
+        if (left > 2) pull();
+        if (left == 2) fetch();
+        if (left > 1) interval(1, true, false, ra1, rb1, left > 2, ra0, rb0);
+        if (left > 2) {
+          fetch();
+          interval(0, true, false, ra0, rb0, false, ra1, rb1);
+        }
+      }
+      // the last k-step of the last stage
+      group((NK - 1) & 1, false, 0, 0);
+      kabs += BK;
+#ifdef DAG_STAMP_INNER
+      if (inner && t == 0) *inner = ((st1 & 0xffffffffull) << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
+#endif
+    } else {
+      pull();
+      fetch();
+    }
   }
 
   flush();  // f32: what the last (partial) chunk holds
@@ -413,166 +635,6 @@ __device__ __forceinline__ void dag_gemm_tile_chain(int flags, int row0, int col
   }
 }
 
-// ---- the launches around the factorisation as tasks: SAME arithmetic per element as kmat_kernel, trmv_n_kernel,
-// trmv_t_kernel, alpha_reduce_kernel and lml_final_kernel (kernels.hip), only the thread -> element mapping is carried
-// over to 512-thread workgroups (two 256-thread halves).  Anything another workgroup of this launch reads is stored
-// write-through.
-template <typename T>
-__device__ __forceinline__ void dag_kmat_tile(const DagLaunch& g, int row0, int col0, T* __restrict__ W, char* smem_raw) {
-  const int d = g.d, n = g.n, np = g.ld, nu2 = g.nu2;
-  const T* X = static_cast<const T*>(g.X);
-  const EvalParams* P = g.P;
-  T* xj = reinterpret_cast<T*>(smem_raw);   // [d][64] scaled rows of the j tile
-  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
-  T* xi = xj + (size_t)d * 64 * (1 + half);  // [d][64] per half
-  const int i0 = row0 + 64 * half, j0 = col0;
-  const bool active = i0 >= j0;  // a 64x64 tile strictly above the diagonal is never stored (kmat_kernel launches lower tiles only)
-  for (int e = t; e < 64 * d; e += 256) {
-    const int row = e / d, k = e - row * d;
-    const T ell = (T)P->ell[k];
-    const int gi = i0 + row, gj = j0 + row;
-    xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] / ell : T(0);
-    if (half == 0) xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
-  }
-  __syncthreads();
-  if (!active) return;
-  const int tx = t & 15, ty = t >> 4;
-  T acc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
-  for (int k = 0; k < d; ++k) {
-    T a[4], b[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const T df = a[r] - b[c];
-        acc[r][c] += df * df;
-      }
-  }
-  const T amp = (T)P->amp, noise = (T)P->noise;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gi = i0 + ty + 16 * r;
-    T* p = W + (size_t)gi * np + j0 + tx * 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int gj = j0 + tx * 4 + c;
-      T v;
-      if (gi < n && gj < n) {
-        v = kmat_entry<T>(acc[r][c], nu2, amp, noise, gi == gj);
-      } else {
-        v = (gi == gj) ? T(1) : T(0);
-      }
-      gstore<true>(p + c, v);
-    }
-  }
-}
-
-// 256-thread block sum inside a 512-thread workgroup: threads >= 256 contribute nothing but join the barriers
-__device__ __forceinline__ double dag_block_sum256(double v, double* red) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0 && wave < 4) red[wave] = v;
-  __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
-}
-
-template <typename T>
-__device__ __forceinline__ void dag_trmv_n(const DagLaunch& g, int row0, const T* __restrict__ Xinv) {
-  // trmv_n_kernel: one wave per row, 4 rows per wave here (32 rows per task)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* y = static_cast<const T*>(g.y);
-  T* w = static_cast<T*>(g.wbuf);
-  for (int q = 0; q < 4; ++q) {
-    const int row = row0 + wave * 4 + q;
-    if (row >= g.ld) continue;
-    double acc = 0;
-    const T* xr = Xinv + (size_t)row * g.ld;
-    for (int k = lane; k <= row && k < g.n; k += 64) acc = __builtin_fma((double)xr[k], (double)y[k], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) gstore<true>(&w[row], (T)acc);
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void dag_trmv_t(const DagLaunch& g, int chunk, int col0, const T* __restrict__ Xinv, char* smem_raw) {
-  // trmv_t_kernel: 64 columns x 4 row groups per 256 threads; two such column groups per task
-  double* red = reinterpret_cast<double*>(smem_raw);  // [2][4][64]
-  const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
-  const int c = t & 63, sgrp = t >> 6;
-  const int np = g.ld;
-  const int cg0 = col0 + 64 * half, j = cg0 + c;
-  const T* w = static_cast<const T*>(g.wbuf);
-  double acc = 0;
-  const int i_begin = chunk * 256, i_end = min(i_begin + 256, np);
-  if (i_end > cg0) {
-    for (int i = i_begin + sgrp; i < i_end; i += 4)
-      if (i >= j) acc = __builtin_fma((double)Xinv[(size_t)i * np + j], (double)w[i], acc);
-  }
-  red[(half * 4 + sgrp) * 64 + c] = acc;
-  __syncthreads();
-  if (sgrp == 0 && i_end > cg0) {
-    const double* r = red + half * 256;
-    gstore<true>(&g.part_t[(size_t)chunk * np + j], r[c] + r[64 + c] + r[128 + c] + r[192 + c]);
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void dag_alpha_reduce(const DagLaunch& g, int blk, char* smem_raw) {
-  // alpha_reduce_kernel, block `blk` of 256 columns (threads 0..255)
-  double* red = reinterpret_cast<double*>(smem_raw);
-  const int np = g.ld, n = g.n;
-  const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
-  const int j = blk * 256 + (int)threadIdx.x;
-  const T* y = static_cast<const T*>(g.y);
-  const T* ldiag = static_cast<const T*>(g.ldiag);
-  T* alpha = static_cast<T*>(g.alpha);
-  double ya = 0, ld = 0;
-  if (threadIdx.x < 256 && j < np) {
-    double a = 0;
-    for (int c = j / 256; c < nchunks; ++c) a += g.part_t[(size_t)c * np + j];
-    const T at = (T)a;
-    alpha[j] = (j < n) ? at : T(0);
-    if (j < n) {
-      ya = (double)y[j] * (double)at;
-      ld = log((double)ldiag[j]);
-    }
-  }
-  const double s1 = dag_block_sum256(ya, red);
-  const double s2 = dag_block_sum256(ld, red);
-  if (threadIdx.x == 0) {
-    double* sums = g.part_t + (size_t)nchunks * np;
-    gstore<true>(&sums[2 * blk], s1);
-    gstore<true>(&sums[2 * blk + 1], s2);
-  }
-}
-
-__device__ __forceinline__ void dag_lml_final(const DagLaunch& g) {
-  if (threadIdx.x == 0) {
-    const int np = g.ld;
-    const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
-    const int nblocks = (np + 255) / 256;
-    const double* sums = g.part_t + (size_t)nchunks * np;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblocks; ++b) {
-      s1 += sums[2 * b];
-      s2 += sums[2 * b + 1];
-    }
-    g.out->yalpha = s1;
-    g.out->logdet = s2;
-    g.out->lml = __builtin_fma(-0.5, s1, -s2) - (double)g.n / 2.0 * log(2.0 * 3.14159265358979323846);
-    atomicOr(&g.out->done, 1);
-  }
-}
-
 // DAG_LEAF_NOINLINE=1 compiles the diagonal block as a function of its own: nothing of it spills in the kernel body then (the
 // callee saves 25 registers on its stack instead).  Round 2 found that build not reproducible run to run and kept it off; the
 // cause (round 3, profiles/r03_leaf_race.txt) was not the call but a race inside leaf_body that every build had -- the helper
@@ -609,7 +671,7 @@ __device__ __forceinline__ void dag_leaf_task(T* W1, T* W2, int ld, int blk, T* 
 // (0.8 us look + 0.5 us fetch + a barrier per task, of 4.4 us fixed cost).  Two LDS control blocks alternate so that the next
 // task can be staged while the current one's is still being read.
 //   ctl block (16 dwords): [0] task index, [1] 0 run / 1 skip / 2 leave, [2] 1 = staged by the early look, [4..15] the task
-template <typename T, int MODE>
+template <typename T>
 __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
   extern __shared__ __align__(16) char smem_raw[];
   int* ctl_base = reinterpret_cast<int*>(smem_raw + DAG_LDS_CTL_OFF);
@@ -730,25 +792,13 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
       } else if ((flags & DAGF_CKINV) && g.Kinv == nullptr) {
         // factorisation-only launch: the K^-1 tiles are not wanted
       } else if (kind == DAG_GEMM_128x64) {
-        dag_gemm_tile<T, 128, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
+        dag_gemm_tile<T, 128, 64, DAG_PIPE_128x64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_64x64) {
-        dag_gemm_tile<T, 64, 64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
+        dag_gemm_tile<T, 64, 64, DAG_PIPE_64x64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_128x128) {
-        dag_gemm_tile<T, 128, 128>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
+        dag_gemm_tile<T, 128, 128, (sizeof(T) == 4 ? DAG_PIPE_F32_128x128 : DAG_PIPE_128x128)>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_32x64) {
         dag_gemm_tile_chain<T>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), g.ld, smem_raw, pull, fetch);
-      } else if constexpr (MODE == DAG_MODE_FULL) {
-        if (kind == DAG_KMAT) {
-          dag_kmat_tile<T>(g, row0, col0, W1, smem_raw);
-        } else if (kind == DAG_TRMV_N) {
-          dag_trmv_n<T>(g, row0, W2);
-        } else if (kind == DAG_TRMV_T) {
-          dag_trmv_t<T>(g, row0, col0, W2, smem_raw);
-        } else if (kind == DAG_ALPHA_REDUCE) {
-          dag_alpha_reduce<T>(g, col0, smem_raw);
-        } else if (kind == DAG_LML_FINAL) {
-          dag_lml_final(g);
-        }
       }
     }
     if (!pulled) pull();
@@ -813,8 +863,7 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
 template <typename T>
 void launch_dag(const DagLaunch& g, int nwg, hipStream_t s) {
   if (g.ntasks <= 0 || nwg <= 0) return;
-  if (g.mode == DAG_MODE_FULL) hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_FULL>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
-  else hipLaunchKernelGGL((dag_kernel<T, DAG_MODE_FACTOR>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
+  hipLaunchKernelGGL((dag_kernel<T>), dim3(nwg), dim3(512), DAG_LDS_BYTES, s, g);
 }
 template void launch_dag<double>(const DagLaunch&, int, hipStream_t);
 template void launch_dag<float>(const DagLaunch&, int, hipStream_t);
@@ -822,8 +871,6 @@ template void launch_dag<float>(const DagLaunch&, int, hipStream_t);
 int dag_stage_depth(bool is_f32) { return is_f32 ? DagGeom<float, 128, 64>::BK : DagGeom<double, 128, 64>::BK; }
 
 static void init_dag_kernels() {
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_FACTOR>), DAG_LDS_BYTES, "dag_kernel<f64>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float, DAG_MODE_FACTOR>), DAG_LDS_BYTES, "dag_kernel<f32>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double, DAG_MODE_FULL>), DAG_LDS_BYTES, "dag_kernel<f64, full>: dynamic LDS limit");
-  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float, DAG_MODE_FULL>), DAG_LDS_BYTES, "dag_kernel<f32, full>: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<double>), DAG_LDS_BYTES, "dag_kernel<f64>: dynamic LDS limit");
+  set_lds_attr(reinterpret_cast<const void*>(&dag_kernel<float>), DAG_LDS_BYTES, "dag_kernel<f32>: dynamic LDS limit");
 }

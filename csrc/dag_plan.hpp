@@ -78,7 +78,6 @@ struct DagCosts {
   double per128_small = 3.9;
   double per128_big128 = 15.0;  // 128x128 tile
   double per128_chain = 1.5;  // 32x64 one-shot tile: one dependent MFMA chain per wave
-  double kmat = 9.0;  // one 128x64 kernel-matrix tile (fp64 exp/sqrt bound: 36 us for the 1056 tiles of n=4096 on 256 CUs)
 };
 
 class DagBuilder {
@@ -107,14 +106,12 @@ class DagBuilder {
   // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
   // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
   // carries the inverse (whole matrix only; the factor L lives in W3)
-  DagPlan build(int blo, int bhi, bool full = false, bool lauum = false, bool rl = false) {
+  DagPlan build(int blo, int bhi, bool lauum = false, bool rl = false) {
     plan_ = DagPlan();
     top_lo_ = blo; top_hi_ = bhi;
-    if (rl && blo == 0 && !full) {
+    if (rl && blo == 0) {
       lauum_split_ = rl_lauum_split_;
       build_rl(bhi, lauum);
-    } else if (full && blo == 0) {
-      build_full(bhi);
     } else {
       const Sub root = rec(blo, bhi, nullptr);
       if (lauum && blo == 0) build_lauum(bhi, root);
@@ -711,62 +708,6 @@ class DagBuilder {
     return out;
   }
 
-  // kmat tiles -> recursion (gated row by row by the tiles of its block row) -> w = X y -> partials of X^T w -> alpha,
-  // y^T alpha, log det -> lml.  Task shapes and reduction orders are those of kmat_kernel / trmv_n_kernel / trmv_t_kernel /
-  // alpha_reduce_kernel / lml_final_kernel, so the results are the launch path's, bit for bit.
-  void build_full(int nb) {
-    const int np = nb * 128;
-    RowGates krow(nb);
-    for (int bi = 0; bi < nb; ++bi) krow[bi] = DagGate{new_counter(), 2 * (bi + 1)};
-    for (int bi = 0; bi < nb; ++bi)
-      for (int tj = 0; tj <= 2 * bi + 1; ++tj) {
-        DagTask t{};
-        t.kind = DAG_KMAT;
-        t.row0 = bi * 128; t.col0 = tj * 64;
-        push(t, {}, krow[bi].cnt, -1, cost_.kmat);
-      }
-    const Sub root = rec(0, nb, &krow);
-    // w = X y, 32 rows per task
-    const int nchunks = (np + 255) / 256;
-    RowGates wchunk(nchunks);
-    for (int c = 0; c < nchunks; ++c) wchunk[c] = DagGate{new_counter(), (std::min(np, 256 * (c + 1)) - 256 * c) / 32};
-    for (int g = 0; g < np / 32; ++g) {
-      DagTask t{};
-      t.kind = DAG_TRMV_N;
-      t.row0 = 32 * g;
-      push(t, {root.rowfin[(32 * g) / 128]}, wchunk[(32 * g) / 256].cnt, -1, cost_.overhead + 0.02 * (32 * g / 128 + 1) * 32 / 8);
-    }
-    // partials of X^T w: chunk c of 256 rows x 128 columns
-    const int nblocks = (np + 255) / 256;
-    RowGates pcol(nblocks);
-    for (int b = 0; b < nblocks; ++b) pcol[b] = DagGate{new_counter(), 0};
-    struct TT { int c, q; };
-    std::vector<TT> tts;
-    for (int c = 0; c < nchunks; ++c) {
-      const int i_end = std::min(256 * (c + 1), np);
-      for (int q = 0; q * 128 < i_end; ++q) {
-        tts.push_back({c, q});
-        pcol[(128 * q) / 256].val++;
-      }
-    }
-    for (const TT& tt : tts) {
-      DagTask t{};
-      t.kind = DAG_TRMV_T;
-      t.row0 = tt.c; t.col0 = 128 * tt.q;
-      push(t, {wchunk[tt.c]}, pcol[(128 * tt.q) / 256].cnt, -1, cost_.overhead + 4.0);
-    }
-    const DagGate rall{new_counter(), nblocks};
-    for (int b = 0; b < nblocks; ++b) {
-      DagTask t{};
-      t.kind = DAG_ALPHA_REDUCE;
-      t.col0 = b;
-      push(t, {pcol[b]}, rall.cnt, -1, cost_.overhead + 2.0);
-    }
-    DagTask f{};
-    f.kind = DAG_LML_FINAL;
-    push(f, {rall}, -1, -1, cost_.overhead);
-  }
-
   // Reorder the queue: simulate a list schedule with nwg_ workers, priority = longest remaining path.
   void order() {
     const int nt = (int)plan_.tasks.size(), nc = (int)plan_.totals.size();
@@ -963,27 +904,6 @@ inline std::string dag_plan_validate(const DagPlan& plan, int nblocks_total) {
       rect(0, b, b + 128, b, b + 128, false);
       rect(1, b, b + 128, b, b + 128, true);
       cell(4, t.row0, 0, true);
-    } else if (t.kind == DAG_KMAT) {
-      for (int h = 0; h < 2; ++h)
-        if (t.row0 + 64 * h >= t.col0) rect(0, t.row0 + 64 * h, t.row0 + 64 * h + 64, t.col0, t.col0 + 64, true);
-    } else if (t.kind == DAG_TRMV_N) {
-      rect(1, t.row0, t.row0 + 32, 0, t.row0 + 32, false);
-      cell(2, t.row0 / 32, 0, true);
-    } else if (t.kind == DAG_TRMV_T) {
-      const int np = nblocks_total * 128, i0 = t.row0 * 256, i1 = std::min(i0 + 256, np);
-      for (int r = i0 / 64; r < i1 / 64; ++r)
-        for (int c = t.col0 / 64; c < t.col0 / 64 + 2; ++c)
-          if (r >= c) rect(1, r * 64, r * 64 + 64, c * 64, c * 64 + 64, false);
-      for (int q = i0 / 32; q < i1 / 32; ++q) cell(2, q, 0, false);
-      cell(3, t.row0, t.col0 / 128, true);
-    } else if (t.kind == DAG_ALPHA_REDUCE) {
-      const int np = nblocks_total * 128, nchunks = (np + 255) / 256;
-      for (int c = t.col0; c < nchunks; ++c)
-        for (int q = 2 * t.col0; q < 2 * t.col0 + 2 && q * 128 < np; ++q) cell(3, c, q, false);
-      for (int k = 2 * t.col0; k < 2 * t.col0 + 2 && k < nblocks_total; ++k) cell(4, k, 0, false);
-      cell(5, t.col0, 0, true);
-    } else if (t.kind == DAG_LML_FINAL) {
-      for (int b = 0; b < (nblocks_total * 128 + 255) / 256; ++b) cell(5, b, 0, false);
     } else {
       const int ta = (t.kind == DAG_GEMM_128x64 || t.kind == DAG_GEMM_128x128) ? 128 : (t.kind == DAG_GEMM_32x64 ? 32 : 64), tb = t.kind == DAG_GEMM_128x128 ? 128 : 64;
       const int ab = (t.flags & DAGF_A3) ? 7 : ((t.flags & DAGF_ABUF) ? 1 : 0), bb = (t.flags & DAGF_B3) ? 7 : ((t.flags & DAGF_BBUF) ? 1 : 0);

@@ -86,13 +86,8 @@ struct GemmLaunch {
 // order of the dependency graph, so any number of resident workgroups >= 1 makes progress (no co-residency needed).
 enum : uint16_t {
   DAG_GEMM_128x64 = 0, DAG_GEMM_64x64 = 1, DAG_LEAF = 2,
-  // the launches around the factorisation, as tasks of the same queue (same per-element arithmetic as the kernels they
-  // replace, so results stay bitwise equal): kernel-matrix tiles in front, the alpha / lml reductions behind
-  DAG_KMAT = 3,          // row0 = first row of a 128-row block, col0 = first column of a 64-column tile
-  DAG_TRMV_N = 4,        // row0 = first of 32 rows of w = X y
-  DAG_TRMV_T = 5,        // row0 = 256-row chunk index, col0 = first of 128 columns of the chunk's partial X^T w
-  DAG_ALPHA_REDUCE = 6,  // col0 = 256-column block index: alpha, partial sums of y^T alpha and log diag(L)
-  DAG_LML_FINAL = 7,
+  // (3..7 were the kernel-matrix tiles and the alpha / lml reductions as tasks of the same queue, rounds 2-4: measured slower
+  // than the launches around the queue, removed in round 5)
   // round 4: a 32x64 output tile whose operands (at most 128 contraction elements at a time, both stored [outer][k]) are
   // fetched in ONE shot -- the two products between consecutive diagonal blocks of the right-looking plan (L(k+1,k) =
   // A(k+1,k) X_kk^T and A(k+1,k+1) -= L(k+1,k) L(k+1,k)^T), where a tile's latency counts and its throughput does not.
@@ -138,14 +133,9 @@ static_assert(DAG_MAXSIG == 3, "DagTask::sig has three entries: dword 5 high hal
 static_assert(sizeof(DagTask) == 48, "DagTask layout");  // dag_kernel decodes it dword by dword: keep the field order
 constexpr int DAG_CTRL_WORDS = 4;     // ctrl[0] queue head, [1] first task that gave up waiting (+1), [2..3] spare; counters follow
 constexpr int DAG_INFO_TIMEOUT = -2;  // written to EvalOut::info when a wait exceeded its bound (a bug, never a data property)
-// Two instantiations of the task-queue kernel: the factorisation's tasks only (the default), or with the kernel-matrix /
-// reduction tasks as well (HBEGP_DAG_FULL).  With everything inlined into one kernel the diagonal block spilled 60 VGPRs
-// (33.5 us per block instead of 27.4).
-enum : int { DAG_MODE_FACTOR = 0, DAG_MODE_FULL = 1 };
 struct DagLaunch {
   const DagTask* tasks;
   int ntasks;
-  int mode;  // DAG_MODE_*
   int* ctrl;
   void* W1;
   void* W2;
@@ -154,15 +144,6 @@ struct DagLaunch {
   int ld;
   void* ldiag;
   int* info;
-  // operands of the kernel-matrix and alpha / lml tasks (null / unused in a factorisation-only plan)
-  const void* X;          // n x d features
-  const void* y;          // np targets (zero padded)
-  const EvalParams* P;
-  int n, d, nu2;
-  void* wbuf;             // w = X y (np)
-  double* part_t;         // chunk partials of X^T w, then the per-block sums (as launch_alpha_lml lays them out)
-  void* alpha;            // np
-  EvalOut* out;
   unsigned long long* trace;  // optional (diagnostics): per task [pulled, inputs ready, computed, published] on the 100 MHz clock, then the CU id
   unsigned long long wait_ticks;  // bound of one dependency wait in ticks of the 100 MHz clock (host: from the plan's simulated makespan)
   int leaf_dbg;                   // debug bits of the diagonal-block tasks (tests: 16 = the helper wave starts late, HBEGP_LEAF_DBG)

@@ -96,7 +96,13 @@ struct DevPool {
   size_t cached = 0;
   static constexpr size_t MAX_CACHED = (size_t)24 << 30;
   void* get(int dev, size_t bytes, bool* fresh) {
-    {
+    // Test switches (tests/test_gpu_parity.py::test_fresh_pool_blocks_are_cleared_before_their_first_writer):
+    //   HBEGP_POOL_FRESH=1         never recycle: every block is a fresh hipMalloc, as in a fresh process
+    //   HBEGP_POOL_NULL_DELAY_MB=N queue an N MiB fill on the null stream in front of every fresh block's clear (makes the
+    //                              clear LATE on purpose: a first writer on a non-blocking stream then runs before it)
+    //   HBEGP_POOL_OLD_CLEAR=1     round 1-4's clear: hipMemset with no synchronisation (the race the test must see fail)
+    const bool always_fresh = getenv("HBEGP_POOL_FRESH") != nullptr && atoi(getenv("HBEGP_POOL_FRESH")) != 0;
+    if (!always_fresh) {
       std::lock_guard<std::mutex> lk(mu);
       auto it = free_list.find({dev, bytes});
       if (it != free_list.end() && !it->second.empty()) {
@@ -117,11 +123,30 @@ struct DevPool {
     // a fresh block is cleared once, here: every later owner may rely on "finite numbers everywhere" (recycled blocks
     // hold finite results of their previous life)
     // hipMemset on device memory returns before the fill has run (it is queued on the null stream), and the engine's streams are
-    // non-blocking ones that do not wait for the null stream: without the synchronisation below a first writer on such a stream
-    // (the model's copy of L^-1 in make_model) can be overtaken by the fill -- seen once in round 4 as a predictive variance that
-    // was off by O(1) on a fresh process, where every block is a fresh one.
-    e = hipMemsetAsync(p, 0, bytes, nullptr);
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    // non-blocking ones that do not wait for the null stream: without the synchronisation below the fill runs CONCURRENTLY with,
+    // or after, the block's first writer on such a stream (the model's copy of L^-1 in make_model, the kernel-matrix tiles of an
+    // evaluation) and zeroes part or all of what was written -- seen once in round 4 as predictive variances that were off by
+    // O(1) on a fresh process, where every block is a fresh one (profiles/r04_memset_race.txt).
+    const int delay_mb = getenv("HBEGP_POOL_NULL_DELAY_MB") ? atoi(getenv("HBEGP_POOL_NULL_DELAY_MB")) : 0;
+    if (delay_mb > 0) {
+      static std::mutex dmu;
+      static std::map<int, std::pair<void*, size_t>> scratch;  // per device, kept for the life of the process (a test switch)
+      std::lock_guard<std::mutex> lk(dmu);
+      auto& sc = scratch[dev];
+      const size_t want = (size_t)delay_mb << 20;
+      if (sc.second < want) {
+        if (sc.first) (void)hipFree(sc.first);
+        sc = {nullptr, 0};
+        if (hipMalloc(&sc.first, want) == hipSuccess) sc.second = want;
+      }
+      if (sc.first) (void)hipMemsetAsync(sc.first, 0x5a, sc.second, nullptr);
+    }
+    if (getenv("HBEGP_POOL_OLD_CLEAR") != nullptr && atoi(getenv("HBEGP_POOL_OLD_CLEAR")) != 0) {
+      e = hipMemset(p, 0, bytes);
+    } else {
+      e = hipMemsetAsync(p, 0, bytes, nullptr);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
     if (e != hipSuccess) {
       (void)hipFree(p);
       throw HipError{e, "hipMemset (pool)", __LINE__};
@@ -390,7 +415,6 @@ struct Slot {
   std::vector<double> best_theta;
   int last_target = 0;  // buffer written by the most recent evaluation
   int dag_variant = 1;  // which ordering / launch size the next task-queue launch uses (Problem::DagVariant)
-  int dag_target = 0;   // alpha buffer the task-queue launch writes (its alpha / lml tasks)
   T* dag_kinv = nullptr;  // K^-1 buffer the task-queue launch writes (its X^T X tiles); null: factorisation only
   int gemm_ord = 0;     // ordinal of the next GEMM launch inside the current evaluation (indexes the static schedules)
   unsigned long long seq = 0;  // serial number of the last evaluation handed to the device (EvalParams::seq)
@@ -419,7 +443,6 @@ struct Problem : ProblemBase {
   std::vector<std::vector<Sched>> scheds;   // [device][gemm launch ordinal]
   // device-scheduled factorisation (dag_kernel.inc.hpp): one plan per problem, the same on every device
   bool dag_ = false;
-  bool dag_full_ = false;                   // the kernel-matrix tiles and the alpha / lml reductions are tasks of the queue too
   bool dag_lauum_ = false;                  // the tiles of K^-1 = X^T X are tasks of the queue too (no LAUUM launch)
   bool dag_rl_ = false;                     // right-looking plan (dag_plan.hpp build_rl): the factor L lives in W3
   double dag_gflop_lauum = 0;
@@ -454,6 +477,10 @@ struct Problem : ProblemBase {
   // waited 52 + 54 + 29 us per evaluation for the host to enqueue the three extra nodes in front of the long kernel, and 84 us
   // between two evaluations.
   bool hostio_ = true;
+  // ONE rule for "this problem's evaluations end by publishing their serial number into the pinned result block": enqueue_eval
+  // acts on it when it runs, run_eval when a graph replay skips enqueue_eval (two copies of the condition could drift apart:
+  // every evaluation would then sit out wait_eval's two-second fallback, or silently fall back to hipStreamSynchronize)
+  bool eval_published() const { return hostio_ && !small_; }
   int leaf_dbg_ = 0;                        // HBEGP_LEAF_DBG: debug bits of the diagonal-block kernel (16: helper waves start late)
 
   // single_shot: the problem runs one evaluation (extend): skip the static schedule tables, every GEMM launch is ad hoc
@@ -585,27 +612,21 @@ struct Problem : ProblemBase {
       };
       // plans depend only on (blocks, stage depth, tiling and ordering knobs): the caller fits one model per generation with
       // slowly growing n, so they are kept (building + simulating the n=4096 queue costs ~15 ms of host time per fit)
-      // HBEGP_DAG_FULL=1: kmat and the alpha / lml reductions as tasks of the same queue instead of launches around it (under
-      // contention those launches take 0.11 + 0.28 ms per evaluation).  Bitwise the same results, but measured SLOWER: 1.485
-      // vs 1.524 fit+predict/s, 2.64 vs 2.55 ms for one evaluation alone -- one 512-thread workgroup per CU gives the fp64
-      // exp/sqrt code of the kernel-matrix tiles a quarter of the occupancy the launch has, and the alpha passes become a
-      // dependent tail on 85 CUs.  Off by default.
-      dag_full_ = env_int("HBEGP_DAG_FULL", 0) != 0;
       // HBEGP_DAG_LAUUM (default 1): the tiles of K^-1 = X^T X follow the recursion in the same queue, as 128x64 tile tasks,
       // instead of a gemm_kernel launch behind the task-queue launch
-      dag_lauum_ = !dag_full_ && env_int("HBEGP_DAG_LAUUM", 1) != 0;
+      dag_lauum_ = env_int("HBEGP_DAG_LAUUM", 1) != 0;
       // HBEGP_DAG_RL: right-looking tile Cholesky + divide-and-conquer inverse instead of the recursion that carries the
       // inverse: two 128-deep tiles between consecutive diagonal blocks instead of products as deep as the node is wide
       // (critical path of one evaluation at n = 4096: 2.83 -> 2.02 ms, simulated).  Not bitwise equal to the launch path
       // (another order of operations); the recursion plan stays available (0) and is what the bitwise tests pin.
       // Above ~10k rows one evaluation is bound by the tile work, where the recursion's deeper tiles win again (n=8192: 10.3 /
       // 9.9 ms recursion / right-looking, 12288: 31.4 / 32.0, 16384: 72.3 / 75.5).
-      dag_rl_ = !dag_full_ && env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
+      dag_rl_ = env_int("HBEGP_DAG_RL", np / NB <= 80 ? 1 : 0) != 0;
       static std::mutex cache_mu;
       static std::map<std::array<int, 20>, std::shared_ptr<const DagPlan>> cache;
       auto plan_for = [&](int nwg) {
         std::array<int, 20> key = {np / NB, dag_stage_depth(is_f32), env_int("HBEGP_DAG_SMALLH", dag_rl_ ? 4 : 8), env_int("HBEGP_DAG_ORDER", 1) ? env_int("HBEGP_DAG_ORDER_WG", nwg) : 0,
-                                   env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), dag_full_ ? 1 : 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
+                                   env_int("HBEGP_DAG_FINE", 1), env_int("HBEGP_DAG_CRIT", 1), 0, dag_lauum_ ? 1 : 0, dag_rl_ ? 1 : 0,
                                    env_int("HBEGP_DAG_RL_GROUP", 32), env_int("HBEGP_DAG_RL_NEAR", 1),
                                    env_int("HBEGP_DAG_LAUUM_SPLIT", n_slots <= 1 ? 1 : 0),
                                    env_int("HBEGP_DAG_CHAIN32", 1),
@@ -641,7 +662,7 @@ struct Problem : ProblemBase {
           builder.set_rl_progressive(key[13] != 0, key[14], key[15], key[16] != 0, key[17]);
           builder.set_chain_bias((double)key[18]);
           builder.set_big128(key[19] != 0, key[19] >= 2);
-          cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_full_, dag_lauum_, dag_rl_));
+          cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_lauum_, dag_rl_));
           std::lock_guard<std::mutex> lk(cache_mu);
           if (cache.size() > 64) cache.clear();
           cache[key] = cached;
@@ -919,12 +940,9 @@ struct Problem : ProblemBase {
       DagLaunch g{};
       const DagVariant& var = dag_var[s.dag_variant];
       g.tasks = var.tasks[di]; g.ntasks = dag_ntasks; g.ctrl = s.dag_ctrl;
-      g.mode = dag_full_ ? DAG_MODE_FULL : DAG_MODE_FACTOR;
       g.W1 = s.W1; g.W2 = s.W2; g.ld = np; g.ldiag = s.ldiag; g.info = &s.dOut->info;
       g.W3 = s.W3;
       g.Kinv = dag_lauum_ ? s.dag_kinv : nullptr;
-      g.X = Xd[di]; g.y = yd[di]; g.P = s.dP; g.n = n; g.d = d; g.nu2 = nu2;
-      g.wbuf = s.wbuf; g.part_t = s.part_t; g.alpha = s.alpha[s.dag_target]; g.out = s.dOut;
       g.trace = s.dag_trace;
       g.wait_ticks = dag_wait_ticks_;
       g.leaf_dbg = leaf_dbg_;
@@ -1017,7 +1035,6 @@ struct Problem : ProblemBase {
     const int nb = np / NB;
     s.gemm_ord = 0;
     const int* info = &s.dOut->info;
-    const bool in_queue = dag_ && dag_full_ && !adhoc_;  // kmat and alpha / lml run as tasks of the factorisation's queue
     if (small_) {
       if (dry_) return;
       if (tm) tm->begin(PhaseTimer::LEAF);
@@ -1026,7 +1043,7 @@ struct Problem : ProblemBase {
       CHECK_LAUNCHES();
       return;
     }
-    const bool hostio = hostio_ && !in_queue;
+    const bool hostio = eval_published();
     if (!dry_) {
       if (hostio) {
         EvalPrologue pro;
@@ -1041,17 +1058,14 @@ struct Problem : ProblemBase {
       } else {
         HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
         launch_reset_out(s.dOut, s.stream);
-        if (!in_queue) {
-          if (tm) tm->begin(PhaseTimer::KMAT);
-          launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
-          if (tm) tm->end();
-        }
+        if (tm) tm->begin(PhaseTimer::KMAT);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+        if (tm) tm->end();
       }
     }
-    s.dag_target = target;
     s.dag_kinv = s.Kinv[target];
     chol_inv(s, di, nb, tm);
-    if (!dry_ && !in_queue) {
+    if (!dry_) {
       if (tm) tm->begin(PhaseTimer::ALPHA);
       launch_alpha_lml<T>(s.W2, np, n, yd[di], s.ldiag, s.wbuf, s.part_t, s.alpha[target], s.dOut, info, s.stream, hostio ? s.tickets : nullptr);
       if (tm) tm->end();
@@ -1121,7 +1135,14 @@ struct Problem : ProblemBase {
           return;
         }
         __builtin_ia32_pause();
-        if ((it & 4095u) == 0 && steady_clock::now() - t0 > seconds(2)) break;
+        if ((it & 4095u) == 0 && steady_clock::now() - t0 > seconds(2)) {
+          // never in normal operation: a faulted kernel, an evaluation longer than two seconds, or a mismatch between what was
+          // captured and what run_eval expects (eval_published) -- say so once, the fallback below still returns the result
+          static std::atomic<bool> said{false};
+          if (!said.exchange(true))
+            fprintf(stderr, "hbegp: an evaluation did not publish its serial number within 2 s; falling back to hipStreamSynchronize\n");
+          break;
+        }
       }
     }
     HIPCHECK(hipStreamSynchronize(s.stream));
@@ -1143,12 +1164,7 @@ struct Problem : ProblemBase {
       HIPCHECK(hipStreamSynchronize(s.stream));
       return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
     }
-    if (dag_ && dag_full_ && !adhoc_) {
-      // the queue also carries the alpha / lml tasks: let them write the alpha buffer that does NOT hold the captured best
-      s.dag_target = s.best_idx < 0 ? 1 - s.last_target : 1 - s.best_idx;
-    } else {
-      launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
-    }
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
     chol_inv(s, di, np / NB, nullptr);
     CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
@@ -1267,7 +1283,7 @@ struct Problem : ProblemBase {
     } else {
       enqueue_eval(s, di, target, want_grad, nullptr);
     }
-    s.published = hostio_ && !small_ && !(dag_ && dag_full_ && !adhoc_);  // what enqueue_eval records when it is not replayed from a graph
+    s.published = eval_published();  // what enqueue_eval records when it is not replayed from a graph (ONE rule for both: eval_published)
     wait_eval(s, t_launch);
     s.last_target = target;
     const int p = d + 2;
@@ -2332,9 +2348,10 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   builder.set_rl_progressive((fine & 16) != 0, -1, -1, false, getenv("HBEGP_DAG_PROG_RATIO") ? atoi(getenv("HBEGP_DAG_PROG_RATIO")) : 0);
   builder.set_chain_bias(getenv("HBEGP_DAG_CHAIN_BIAS") ? atof(getenv("HBEGP_DAG_CHAIN_BIAS")) : 0.0);
   builder.set_big128(getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) != 0, getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) >= 2);
-  // bit 1: kernel-matrix tiles and alpha / lml reductions as tasks too; bit 2: the K^-1 = X^T X tiles behind the recursion;
-  // bit 3: the right-looking plan; bit 4: its row-progressive inverse and K^-1
-  DagPlan plan = builder.build(0, nblocks, (fine & 2) != 0, (fine & 4) != 0, (fine & 8) != 0);
+  // bit 1: unused (rounds 2-4: kernel-matrix tiles and alpha / lml reductions as tasks too); bit 2: the K^-1 = X^T X tiles behind
+  // the recursion; bit 3: the right-looking plan; bit 4: its row-progressive inverse and K^-1
+  if (fine & 2) return fail(HBEGP_EINVAL, "fine bit 1 (kernel-matrix / reduction tasks in the queue) no longer exists");
+  DagPlan plan = builder.build(0, nblocks, (fine & 4) != 0, (fine & 8) != 0);
   // fault injection for the validator's own test: HBEGP_DAG_TEST_FAULT = "drop:<i>" (task i loses its first wait) or
   // "move:<i>:<j>" (task i is moved to queue position j)
   if (const char* fault = getenv("HBEGP_DAG_TEST_FAULT")) {

@@ -14,7 +14,7 @@
 #pragma once
 #include <cmath>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define LBFGS_HD __host__ __device__
 #else
 #define LBFGS_HD

@@ -205,8 +205,8 @@ int hbegp_problem_debug_get_f32(hbegp_problem* prob, int dev, int slot, int whic
 /* ---- test hook (host only, no GPU): build the task queue of the device-scheduled factorisation for `nblocks`
  * 128-blocks (bk = contraction elements per stage: 16 for f64, 32 for f32; nodes up to small_h blocks wide use 64x64
  * tiles; nwg > 0: order the queue by a list schedule simulated for nwg workgroups; fine bit 0: per-row-block dependencies,
- * bit 1: the kernel-matrix tiles and the alpha / lml reductions are tasks of the queue too, bit 2: the tiles of
- * K^-1 = X^T X follow in the same queue, bit 3: the right-looking plan instead of the recursion) and
+ * bit 1: must be 0 (a plan variant removed in round 5), bit 2: the tiles of K^-1 = X^T X follow in the same queue,
+ * bit 3: the right-looking plan instead of the recursion, bit 4: its row-progressive inverse and K^-1) and
  * check it: queue order topological (=> deadlock-free for any number of resident workgroups), every wait for a full
  * count, no unordered access to a tile.  crit_us / sim_us: critical path and simulated makespan under the host's task
  * time estimates.  Returns HBEGP_OK or HBEGP_EINVAL with the reason in err. */

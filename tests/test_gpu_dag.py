@@ -212,19 +212,6 @@ def test_split_kinv_tiles_continue_the_same_accumulation(n, monkeypatch):
         assert np.array_equal(a0, a1) and np.array_equal(k0, k1) and np.array_equal(l0, l1)
 
 
-def test_full_mode_queue_matches_launch_path(monkeypatch):
-    # HBEGP_DAG_FULL=1 (off by default: measured slower): the kernel-matrix tiles and the alpha / lml reductions are tasks of the
-    # queue too.  Same per-element arithmetic as the launches they replace: lml, gradient, alpha and K^-1 equal the launch path's.
-    w = synth.make_workload("M", n=700)
-    X, y, theta = w["X"], w["y"], w["theta"]
-    ref = _eval_all(X, y, theta, monkeypatch, "0")
-    got = _eval_all(X, y, theta, monkeypatch, "1", HBEGP_DAG_FULL=1, HBEGP_DAG_VALIDATE=1)
-    for (r0, (a0, k0, l0)), (r1, (a1, k1, l1)) in zip(ref, got):
-        assert r0 is not None and r1 is not None
-        assert _close(r0[0], r1[0], 1e-13) and _close(r0[1], r1[1], 1e-13)
-        assert _close(a0, a1, 1e-13) and _close(k0, k1, 1e-13) and _close(l0, l1, 1e-13)
-
-
 def _bits_equal(a, b):
     (ra, (aa, ka, la)), (rb, (ab, kb, lb)) = a, b
     return ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(aa, ab) and np.array_equal(np.tril(ka), np.tril(kb)) and np.array_equal(la, lb)

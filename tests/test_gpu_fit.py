@@ -10,6 +10,8 @@ import pytest
 from hbetune_rs_amd import gpr, synth
 from oracle import gpr_oracle as O
 
+import parity_rules as PR
+
 pytestmark = pytest.mark.gpu
 KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
 
@@ -33,6 +35,9 @@ def test_reference_simple_fit_kat():
 
 
 def test_fit_trace_replays_on_oracle_and_capture_rule():
+    # EVERY evaluation of the fit is replayed on the oracle (lml.rs:29-79 through fit.rs:93-134) at the plain 1e-8; where the
+    # oracle's own digits end (the optimiser visits corners with tiny noise and long length scales) the extended-precision
+    # referee decides: |gpu - truth| <= max(1e-8 scale, 2 |lapack - truth|)   (tests/parity_rules.py)
     w = synth.make_workload("C2", n=256)
     X, y = w["X"], w["y"]
     starts = synth.restart_points("C2", w["lo"], w["hi"], 2)
@@ -41,40 +46,40 @@ def test_fit_trace_replays_on_oracle_and_capture_rule():
     assert len(tr["lml"]) <= 3 * 40 and set(tr["run"].tolist()) == {0, 1, 2}
     bounds = list(zip(w["lo"], w["hi"]))
     best = -math.inf
-    checked = 0
-    eps = np.finfo(np.float64).eps
-    worst = {"lml": 0.0, "grad": 0.0, "cond": 0.0}
+    judge = PR.Judge(PR.TOL64)
     for i in range(len(tr["lml"])):
         th = tr["theta"][i]
         assert np.all(th >= np.log(w["lo"]) - 1e-12) and np.all(th <= np.log(w["hi"]) + 1e-12)
-        if i % 3 == 0:  # replay a third of the evaluations on the CPU oracle
-            f, g, res = O.objective(th, X, y, 2.5, bounds)
-            if res is None:
-                assert tr["lml"][i] == -math.inf
-            else:
-                # the north star's 1e-8, relative to max(1, scale) -- unless cond(K) at this theta puts the ORACLE's own digits
-                # beyond it: both sides solve with K, so neither is good to better than ~cond(K) eps; the allowance then is
-                # 100 cond(K) eps (the optimiser does visit such corners of the box: tiny noise, long length scales)
-                cond = float(np.linalg.cond(res["kernel_matrix"]))
-                bar = max(1e-8, 100.0 * cond * eps)
-                dl = abs(-f - tr["lml"][i]) / max(1.0, abs(f))
-                dg = float(np.max(np.abs(tr["grad"][i] + g))) / max(1.0, np.abs(g).max())
-                assert dl <= bar and dg <= bar, (i, dl, dg, cond, bar)
-                worst = {"lml": max(worst["lml"], dl), "grad": max(worst["grad"], dg), "cond": max(worst["cond"], cond)}
-            checked += 1
+        f, g, res = O.objective(th, X, y, 2.5, bounds)
+        if res is None:
+            assert tr["lml"][i] == -math.inf
+        else:
+            rf = []  # built on first use, shared by the two comparisons of this theta
+
+            def truth(kind, th=th, rf=rf):
+                if not rf:
+                    rf.append(PR.referee_for(X, y, th, bounds))
+                return np.array([rf[0].lml()]) if kind == "lml" else rf[0].gradient()
+
+            judge.check(f"lml of evaluation {i}", [tr["lml"][i]], [-f], lambda: truth("lml"))
+            judge.check(f"gradient of evaluation {i}", tr["grad"][i], -g, lambda: truth("grad"))
+            if rf:
+                rf[0].close()
         best = max(best, tr["lml"][i])
-    print(f"trace replay: {checked} evaluations on the oracle, worst deviation / scale: lml {worst['lml']:.2e}, gradient {worst['grad']:.2e}; "
-          f"largest cond(K) along the trajectory {worst['cond']:.2e}")
-    assert checked > 10
+    print("trace replay, every evaluation: " + judge.summary())
+    assert judge.n_plain + judge.n_refereed >= 2 * 30
     # capture = arg-max over every evaluation of every run (fit.rs:116-125)
     assert fk.lml == best
     # the model's alpha / K^-1 belong to the captured theta
     i_best = int(np.argmax(tr["lml"]))
     f, g, res = O.objective(tr["theta"][i_best], X, y, 2.5, bounds)
     alpha, kinv = fk.arrays()
-    bar = max(1e-8, 100.0 * float(np.linalg.cond(res["kernel_matrix"])) * eps)
-    np.testing.assert_allclose(alpha, res["alpha"], rtol=0, atol=bar * max(1.0, np.abs(res["alpha"]).max()))
-    np.testing.assert_allclose(kinv, res["k_inv"], rtol=0, atol=bar * max(1.0, np.abs(res["k_inv"]).max()))
+    rf = PR.referee_for(X, y, tr["theta"][i_best], bounds)
+    jm = PR.Judge(PR.TOL64)
+    jm.check("alpha of the fitted model", alpha, res["alpha"], lambda: sum(rf.alpha()))
+    jm.check("K^-1 of the fitted model", kinv, res["k_inv"], lambda: sum(rf.kinv()))
+    print("fitted model: " + jm.summary())
+    rf.close()
     # fitting must improve on the start point
     assert fk.lml > tr["lml"][0]
 
@@ -315,34 +320,56 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
     if fixed_work:
         assert fk.n_evals == 4 * maxeval
     assert np.all(np.diff(tr["run"]) >= 0)  # run by run
-    tol = 1e-8 if dtype == np.float64 else 1e-4
+    # EVERY traced evaluation against the oracle of the element type (f64: LAPACK d*, f32: LAPACK s* -- the reference's own
+    # arithmetic for --use-32) at the plain bar (1e-8 / 1e-4); beyond it the referee decides (tests/parity_rules.py):
+    # |gpu - truth| <= max(bar * scale, 2 |lapack - truth|).  Where LAPACK f32 cannot factor K at all the reference has no digits
+    # and any answer of the engine stands; the engine may say "not positive definite" where LAPACK f32 still returns numbers only
+    # if those numbers have less than two digits in common with the truth.
+    tol = PR.TOL64 if dtype == np.float64 else PR.TOL32
     bounds = list(zip(w["lo"], w["hi"]))
     X64, y64 = X.astype(np.float64), y.astype(np.float64)
-    eps = np.finfo(np.float64).eps
-    for i in range(0, len(tr["lml"]), 3):
+    judge = PR.Judge(tol)
+    n_lapack_failed = n_gpu_only_failed = 0
+    for i in range(len(tr["lml"])):
         th = tr["theta"][i]
         assert np.all(th >= np.log(w["lo"]) - 1e-12) and np.all(th <= np.log(w["hi"]) + 1e-12)
-        f, g, res = O.objective(th, X64, y64, 2.5, bounds)
+        f, g, res = O.objective(th, X, y, 2.5, bounds)  # the oracle in the problem's element type
         if res is None:
-            assert tr["lml"][i] == -math.inf
+            n_lapack_failed += 1
+            if dtype == np.float64:
+                assert tr["lml"][i] == -math.inf
             continue
-        # the bar of the element type, unless cond(K) at this theta puts the arithmetic's own digits beyond it (the optimiser
-        # visits corners of the box with tiny noise): then 100 cond eps (f64) / 10 cond eps (f32: the f32 path accumulates in f64)
-        cond = float(np.linalg.cond(res["kernel_matrix"]))
-        bar = max(tol, 100.0 * cond * eps) if dtype == np.float64 else max(tol, 10.0 * cond * float(np.finfo(np.float32).eps))
-        if dtype == np.float32 and tr["lml"][i] == -math.inf and cond * float(np.finfo(np.float32).eps) > 1e-2:
-            continue  # numerically singular in f32 (the f64 oracle still factors it): "not positive definite" is the f32 answer
-        assert abs(-f - tr["lml"][i]) <= bar * max(1.0, abs(f)), (i, f, tr["lml"][i])
-        np.testing.assert_allclose(tr["grad"][i], -g, rtol=0, atol=bar * max(1.0, np.abs(g).max()))
+        rf = []
+
+        def truth(kind, th=th, rf=rf):
+            if not rf:
+                rf.append(PR.referee_for(X64, y64, th, bounds))
+            return np.array([rf[0].lml()]) if kind == "lml" else rf[0].gradient()
+
+        if tr["lml"][i] == -math.inf:
+            assert dtype == np.float32, (i, f)
+            t_l = truth("lml")[0]
+            assert abs(-f - t_l) > 1e-2 * max(1.0, abs(t_l)), (i, f, t_l)  # LAPACK f32's own answer is noise here
+            n_gpu_only_failed += 1
+        else:
+            judge.check(f"lml of evaluation {i}", [tr["lml"][i]], [-f], lambda: truth("lml"))
+            judge.check(f"gradient of evaluation {i}", tr["grad"][i], -g, lambda: truth("grad"))
+        if rf:
+            rf[0].close()
+    print(f"persistent fit, every evaluation ({np.dtype(dtype).name}): " + judge.summary() +
+          f"; LAPACK failed at {n_lapack_failed}, the engine alone at {n_gpu_only_failed}")
     assert fk.lml == tr["lml"].max()  # capture = arg-max over every evaluation of every run
     i_best = int(np.argmax(tr["lml"]))
-    f, g, res = O.objective(tr["theta"][i_best], X64, y64, 2.5, bounds)
+    f, g, res = O.objective(tr["theta"][i_best], X, y, 2.5, bounds)
     alpha, kinv = fk.arrays()
-    cond_best = float(np.linalg.cond(res["kernel_matrix"]))
-    bar_best = max(1e-7, 100.0 * cond_best * eps) if dtype == np.float64 else max(2e-3, 10.0 * cond_best * float(np.finfo(np.float32).eps))
-    if bar_best < 0.05:  # (an f32 fit that ends at a numerically singular K has no digits of alpha in common with f64)
-        np.testing.assert_allclose(alpha, res["alpha"], rtol=0, atol=bar_best * max(1.0, np.abs(res["alpha"]).max()))
-        np.testing.assert_allclose(kinv, res["k_inv"], rtol=0, atol=bar_best * max(1.0, np.abs(res["k_inv"]).max()))
+    assert np.all(np.isfinite(alpha)) and np.all(np.isfinite(kinv))
+    if res is not None:  # (LAPACK f32 failing at the theta the engine captured: the reference has no digits there)
+        rf = PR.referee_for(X64, y64, tr["theta"][i_best], bounds)
+        jm = PR.Judge(tol)
+        jm.check("alpha of the fitted model", alpha, res["alpha"], lambda: sum(rf.alpha()))
+        jm.check("K^-1 of the fitted model", kinv, res["k_inv"], lambda: sum(rf.kinv()))
+        print("fitted model: " + jm.summary())
+        rf.close()
     mean, var, _ = fk.predict(X[:5])
     assert np.all(np.isfinite(mean)) and np.all(var >= 0)
     lml_dev, n_dev = fk.lml, fk.n_evals

@@ -402,3 +402,56 @@ def test_single_launch_path_for_the_reference_regime(n, d, nu, dtype, monkeypatc
     rm, rv, _ = O.predict(small["Xs"].astype(np.float64), X64, ref["alpha"], ref["k_inv"], c, ell, nu)
     np.testing.assert_allclose(small["mean"], rm, rtol=0, atol=tol * max(1.0, np.abs(rm).max()))
     np.testing.assert_allclose(small["var"], rv, rtol=0, atol=tol * c * (10 if dtype == np.float32 else 1))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fresh_pool_blocks_are_cleared_before_their_first_writer(dtype, monkeypatch):
+    # Round 4's intermittent wrong variance (profiles/r04_memset_race.txt), made deterministic.  A fresh pool block is cleared
+    # once; hipMemset on device memory is queued on the NULL stream and returns at once, while the engine's streams are
+    # non-blocking ones that do not wait for the null stream -- the clear could land on top of (or concurrently with) the block's
+    # first writer.  HBEGP_POOL_FRESH=1 makes every block a fresh one (as in a fresh process), HBEGP_POOL_NULL_DELAY_MB queues a
+    # long fill in front of every clear so that an unsynchronised clear is LATE for certain.  The launch path (n = 589: five
+    # 128-blocks) has no other null-stream synchronisation between the pool and the first launch.
+    #   (a) the shipped clear (hipMemsetAsync + hipStreamSynchronize(nullptr)): oracle results at the plain bar;
+    #   (b) HBEGP_POOL_OLD_CLEAR=1 (round 1-4's hipMemset alone): the model is damaged -- if it were NOT, the diagnosis of
+    #       round 4 would be wrong and that failure still open.
+    n, d = 589, 5
+    w = synth.make_workload("C2", n=n)
+    rng = np.random.default_rng(589)
+    X = rng.random((n, d)).astype(dtype)
+    y = w["y"][:n].astype(dtype)
+    theta = np.concatenate([[math.log(0.05), 0.0], np.log(np.full(d, 0.6))])
+    s2, c, ell = split_theta(theta)
+    Xs = rng.random((5, d)).astype(dtype)
+    ref = O.extend(X.astype(np.float64), y.astype(np.float64), s2, c, ell, 2.5)
+    rm, rv, _ = O.predict(Xs.astype(np.float64), X.astype(np.float64), ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    tol = F64_TOL if dtype == np.float64 else F32_TOL
+    monkeypatch.setenv("HBEGP_POOL_FRESH", "1")
+    monkeypatch.setenv("HBEGP_POOL_NULL_DELAY_MB", "8192")
+
+    def run():
+        fk = gpr.FittedKernel.extend(X, y, theta)
+        try:
+            mean, var, _ = fk.predict(Xs)
+            alpha, _ = fk.arrays()
+        finally:
+            fk.release()
+        return (float(np.max(np.abs(mean - rm))) / max(1.0, np.abs(rm).max()), float(np.max(np.abs(var - np.maximum(rv, 0)))) / c,
+                float(np.max(np.abs(alpha - ref["alpha"]))) / max(1.0, np.abs(ref["alpha"]).max()))
+
+    devs = run()
+    assert max(devs) <= tol, devs
+    monkeypatch.setenv("HBEGP_POOL_OLD_CLEAR", "1")
+    old = None
+    try:
+        old = run()
+        damaged = not (max(old) <= tol)  # NaN counts as damaged
+    except gpr.HbegpError:
+        damaged = True  # e.g. "not positive definite": the kernel matrix was zeroed under the factorisation
+    finally:
+        # drain the null stream (late clears may still be queued) before any other test recycles these blocks: every fresh block
+        # of the shipped path waits for the null stream
+        monkeypatch.delenv("HBEGP_POOL_OLD_CLEAR")
+        again = run()
+    assert damaged, f"the unsynchronised clear did not damage the model (deviations {old}): round 4's diagnosis does not hold"
+    assert max(again) <= tol, again

@@ -8,7 +8,7 @@ int main(int argc, char** argv) {
   const int nb = argc > 1 ? atoi(argv[1]) : 32, nwg = argc > 2 ? atoi(argv[2]) : 96, bk = argc > 3 ? atoi(argv[3]) : 16;
   DagBuilder b(bk, 4, nwg, true, 1);
   b.set_rl(32, 1, false);
-  DagPlan p = b.build(0, nb, false, true, true);
+  DagPlan p = b.build(0, nb, true, true);
   std::map<std::pair<int, int>, std::pair<int, double>> h;
   double tot = 0;
   for (const DagTask& t : p.tasks) {
