@@ -156,9 +156,10 @@ int dag_stage_depth(bool is_f32);  // contraction elements per pipeline stage of
 template <typename T>
 void launch_gemm(const GemmLaunch& g, int tile, hipStream_t s);  // tile in {32, 64, 128}
 
+// queue (kmat, gradtrace): a device int that is zero between launches -- the launch's tiles are dealt through it (kernels.hip)
 template <typename T>
 void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s,
-                 const EvalPrologue* pro = nullptr);
+                 int* queue, const EvalPrologue* pro = nullptr);
 
 // Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag;
 // W3 (optional): the lower triangle of L_blk itself.
@@ -176,7 +177,7 @@ template <typename T>
 // ticket (device int, zero between launches): the launch's last workgroup finalises the gradient itself and, with hout, copies
 // the result block to the pinned one and publishes the evaluation's serial number -- no finalize / publish launches behind it
 void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
-                      double* part, EvalOut* out, const int* info, hipStream_t s, int* ticket = nullptr, EvalOut* hout = nullptr);
+                      double* part, EvalOut* out, const int* info, hipStream_t s, int* queue, int* ticket = nullptr, EvalOut* hout = nullptr);
 size_t gradtrace_part_elems(int np, int d);
 
 template <typename T>

@@ -398,7 +398,7 @@ struct Slot {
   double *part_t = nullptr, *part_g = nullptr;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
-  int* tickets = nullptr;    // [0] alpha / lml reduction, [1] gradient: "last workgroup finishes the launch's job" counters (zero between launches)
+  int* tickets = nullptr;    // [0] alpha / lml reduction, [1] gradient: "last workgroup finishes the launch's job" counters; [2] kernel-matrix, [3] gradient: tile queues (all zero between launches)
   unsigned long long* dag_trace = nullptr;  // HBEGP_DAG_TRACE: per-task time stamps of the last evaluation
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
@@ -1053,13 +1053,13 @@ struct Problem : ProblemBase {
           s.ctrl_cleared = true;
         }
         if (tm) tm->begin(PhaseTimer::KMAT);
-        launch_kmat<T>(Xd[di], n, d, np, nu2, s.hP, s.W1, info, s.stream, &pro);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.hP, s.W1, info, s.stream, s.tickets + 2, &pro);
         if (tm) tm->end();
       } else {
         HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
         launch_reset_out(s.dOut, s.stream);
         if (tm) tm->begin(PhaseTimer::KMAT);
-        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream, s.tickets + 2);
         if (tm) tm->end();
       }
     }
@@ -1086,12 +1086,13 @@ struct Problem : ProblemBase {
     bool fuse_grad = false;
     if (want_grad) {
       if (tm) tm->begin(PhaseTimer::GRAD);
-      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation -- where the launch is a
-      // few hundred workgroups (latency-bound sizes).  Every workgroup drains its write-through partials before it takes its
-      // ticket (~2 us at the end of its life): with the 2,080 workgroups of n = 4096 queueing for the ~60 CUs the other two
-      // task-queue launches leave free that made the launch 138 -> 182 us; there the two tiny launches behind it are free.
-      fuse_grad = hostio && (np / 64) * (np / 64 + 1) / 2 <= 512;
-      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream,
+      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation.  Since round 5 the launch is
+      // queue-fed: a workgroup drains its write-through partials ONCE, when it has run out of tiles, and workgroups that found
+      // the queue empty take no part (round 4: one drain per tile-workgroup -- 2,080 at n = 4096 -- made the fused form slower
+      // there: 138 -> 182 us inside a fit, so it was limited to 512 tiles).  HBEGP_FUSE_GRAD_MAX_TILES overrides.
+      static const int fuse_max = env_int("HBEGP_FUSE_GRAD_MAX_TILES", 1 << 30);
+      fuse_grad = hostio && (np / 64) * (np / 64 + 1) / 2 <= fuse_max;
+      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream, s.tickets + 3,
                           fuse_grad ? s.tickets + 1 : nullptr, fuse_grad ? s.hOut : nullptr);
       if (tm) tm->end();
     }
@@ -1164,7 +1165,7 @@ struct Problem : ProblemBase {
       HIPCHECK(hipStreamSynchronize(s.stream));
       return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
     }
-    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream, s.tickets + 2);
     chol_inv(s, di, np / NB, nullptr);
     CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
@@ -1203,7 +1204,7 @@ struct Problem : ProblemBase {
     HIPCHECK(hipMemcpy2DAsync(s.W2, sizeof(T) * np, pXinv, sizeof(T) * pnp, sizeof(T) * w, w, hipMemcpyDeviceToDevice, s.stream));
     HIPCHECK(hipMemcpy2DAsync(s.Kinv[0], sizeof(T) * np, pKinv, sizeof(T) * pnp, sizeof(T) * w, w, hipMemcpyDeviceToDevice, s.stream));
     HIPCHECK(hipMemcpyAsync(s.ldiag, pldiag, sizeof(T) * w, hipMemcpyDeviceToDevice, s.stream));
-    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream, s.tickets + 2);
     const bool was_adhoc = adhoc_;
     adhoc_ = true;
     try {
@@ -2201,7 +2202,7 @@ static int problem_kmat(hbegp_problem* prob, int dev, int slot, const double* th
   theta_to_params(theta, lo, hi, p->d, s.hP);
   HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
   launch_reset_out(s.dOut, s.stream);
-  launch_kmat<T>(p->Xd[dev], p->n, p->d, p->np, p->nu2, s.dP, s.W1, &s.dOut->info, s.stream);
+  launch_kmat<T>(p->Xd[dev], p->n, p->d, p->np, p->nu2, s.dP, s.W1, &s.dOut->info, s.stream, s.tickets + 2);
   CHECK_LAUNCHES();
   const int n = p->n, np = p->np;
   std::vector<T> tmp((size_t)np * np);

@@ -1088,103 +1088,148 @@ __device__ __forceinline__ void eval_prologue(const EvalParams* __restrict__ P, 
   for (int i = t; i < pro.ctrl_words / 4; i += 256) c4[i] = int4{0, 0, 0, 0};
 }
 
-// 64x64 tile per workgroup; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.  NU2: the Matern order at
-// compile time (no branch per entry); tiles that lie wholly inside the n x n matrix skip the per-entry bounds tests.
+// ---- what kmat_kernel and gradtrace_kernel share (round 5) --------------------------------------------------------------
+// Tiles of 64x64 entries; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.
+//  * The tiles of a launch are dealt through a QUEUE (one returning atomic per tile): the launches used to have one workgroup
+//    per tile -- 2,080 of them at n = 4096, 2,048 resident at once and 32 left over that ran a second, nearly empty round; and
+//    inside a fit only the CUs no task-queue workgroup sits on are free, a number that changes while the launch runs.
+//    The workgroup that draws the very last ticket (ntiles + gridDim.x - 1) leaves the counter at zero for the next launch.
+//  * The j tile's features sit in the LDS so that a thread's four columns are ONE conflict-free 16-byte read (f32) or two
+//    (f64: [k][half][tx][2] -- a 16-lane group then reads 256 contiguous bytes); the plain [k][64] layout made the f64 reads
+//    2-way conflicted (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 45 % in kmat, 20 % in gradtrace, profiles/r04_pmc_sq.json).
+template <typename T>
+__device__ __forceinline__ int xj_index(int k, int col) {  // LDS element index of feature k of column `col` (0..63) of the j tile
+  if constexpr (sizeof(T) == 8) return k * 64 + ((col >> 1) & 1) * 32 + (col >> 2) * 2 + (col & 1);
+  else return k * 64 + col;
+}
+template <typename T>
+__device__ __forceinline__ void read_xj4(const T* xj, int k, int tx, T (&b)[4]) {  // features k of columns 4 tx .. 4 tx + 3
+  if constexpr (sizeof(T) == 8) {
+    const d2 lo = *reinterpret_cast<const d2*>(xj + k * 64 + tx * 2), hi = *reinterpret_cast<const d2*>(xj + k * 64 + 32 + tx * 2);
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = hi[0]; b[3] = hi[1];
+  } else {
+    const f4 v = *reinterpret_cast<const f4*>(xj + k * 64 + tx * 4);
+    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+  }
+}
+// next tile of the launch (uniform), or -1; ends with a barrier, so the previous tile's LDS operands are free to be overwritten
+__device__ __forceinline__ int next_tile(int* queue, int ntiles, int* s_tile) {
+  if (threadIdx.x == 0) {
+    int tk = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == ntiles + (int)gridDim.x - 1) __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the last ticket of the launch
+    *s_tile = tk < ntiles ? tk : -1;
+  }
+  __syncthreads();
+  return *s_tile;
+}
+
+// NU2: the Matern order at compile time (no branch per entry); tiles that lie wholly inside the n x n matrix skip the
+// per-entry bounds tests.
 template <typename T, int NU2>
 __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int n, int d, int np,
                                                    const EvalParams* __restrict__ P, T* __restrict__ W,
-                                                   const int* info, EvalPrologue pro) {
+                                                   const int* info, EvalPrologue pro, int* queue, int ntiles) {
   if (pro.dP) {
     // first kernel of an evaluation (engine.hpp, EvalPrologue): nothing has failed yet, `info` still holds the previous
     // evaluation's value and is not read; workgroup 0 prepares the device-side blocks for the kernels behind this one
     if (blockIdx.x == 0) eval_prologue(P, pro);
   } else if (*info != 0) {
+    // the queue is not touched: it stays at zero for the next launch
     return;
   }
   extern __shared__ __align__(16) char smem_raw[];
   T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] scaled rows of the i tile (feature-major)
-  T* xj = xi + (size_t)d * 64;             // [d][64]
-  const int li = tri_row(blockIdx.x), lj = blockIdx.x - li * (li + 1) / 2;
-  const int i0 = li * 64, j0 = lj * 64;
+  T* xj = xi + (size_t)d * 64;             // [d] x 64 columns of the j tile, xj_index layout
   const int t = threadIdx.x;
   // the parameters once per workgroup: in an evaluation driven through pinned memory P is a host block, and every read of it is
   // an uncached round trip over the host link (per-thread reads made the launch 10 us longer at n=4096)
   __shared__ double sp[MAXP];
+  __shared__ int s_tile;
   if (t < d + 2) sp[t] = reinterpret_cast<const double*>(P)[t];
   static_assert(offsetof(EvalParams, noise) == 0 && offsetof(EvalParams, amp) == 8 && offsetof(EvalParams, ell) == 16, "EvalParams: noise, amp, ell[]");
-  __syncthreads();
-  for (int e = t; e < 64 * d; e += 256) {
-    const int row = e / d, k = e - row * d;
-    const T ell = (T)sp[2 + k];  // A::from_f (matern_kernel.rs:50)
-    const int gi = i0 + row, gj = j0 + row;
-    xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] / ell : T(0);  // matern_kernel.rs:51-60
-    xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
-  }
-  __syncthreads();
   const int tx = t & 15, ty = t >> 4;
-  T acc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
-  for (int k = 0; k < d; ++k) {  // cdist accumulation order (matern_kernel.rs:274-278)
-    T a[4], b[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+  typedef T vec4 __attribute__((ext_vector_type(4)));
+  for (;;) {
+    const int tile = next_tile(queue, ntiles, &s_tile);  // (its barrier also orders the reads of sp behind their writes)
+    if (tile < 0) break;
+    const int li = tri_row(tile), lj = tile - li * (li + 1) / 2;
+    const int i0 = li * 64, j0 = lj * 64;
+    for (int e = t; e < 64 * d; e += 256) {
+      const int row = e / d, k = e - row * d;
+      const T ell = (T)sp[2 + k];  // A::from_f (matern_kernel.rs:50)
+      const int gi = i0 + row, gj = j0 + row;
+      xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] / ell : T(0);  // matern_kernel.rs:51-60
+      xj[xj_index<T>(k, row)] = (gj < n) ? X[(size_t)gj * d + k] / ell : T(0);
+    }
+    __syncthreads();
+    T acc[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const T df = a[r] - b[c];
-        acc[r][c] += df * df;
+      for (int c = 0; c < 4; ++c) acc[r][c] = T(0);
+    for (int k = 0; k < d; ++k) {  // cdist accumulation order (matern_kernel.rs:274-278)
+      T a[4], b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
+      read_xj4<T>(xj, k, tx, b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const T df = a[r] - b[c];
+          acc[r][c] += df * df;
+        }
+    }
+    const T amp = (T)sp[1], noise = (T)sp[0];
+    if (i0 + 64 <= n && j0 + 64 <= n) {
+      const bool dtile = li == lj;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + ty + 16 * r;
+        vec4 out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = kmat_entry<T>(acc[r][c], NU2, amp, noise, dtile && gi == j0 + tx * 4 + c);
+        *reinterpret_cast<vec4*>(W + (size_t)gi * np + j0 + tx * 4) = out;
       }
-  }
-  const T amp = (T)sp[1], noise = (T)sp[0];
-  typedef T vec4 __attribute__((ext_vector_type(4)));
-  if (i0 + 64 <= n && j0 + 64 <= n) {
-    const bool dtile = li == lj;
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int gi = i0 + ty + 16 * r;
       vec4 out;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) out[c] = kmat_entry<T>(acc[r][c], NU2, amp, noise, dtile && gi == j0 + tx * 4 + c);
+      for (int c = 0; c < 4; ++c) {
+        const int gj = j0 + tx * 4 + c;
+        const T v = kmat_entry<T>(acc[r][c], NU2, amp, noise, gi == gj);
+        out[c] = (gi < n && gj < n) ? v : ((gi == gj) ? T(1) : T(0));  // identity padding
+      }
       *reinterpret_cast<vec4*>(W + (size_t)gi * np + j0 + tx * 4) = out;
     }
-    return;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int gi = i0 + ty + 16 * r;
-    vec4 out;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int gj = j0 + tx * 4 + c;
-      const T v = kmat_entry<T>(acc[r][c], NU2, amp, noise, gi == gj);
-      out[c] = (gi < n && gj < n) ? v : ((gi == gj) ? T(1) : T(0));  // identity padding
-    }
-    *reinterpret_cast<vec4*>(W + (size_t)gi * np + j0 + tx * 4) = out;
-  }
+}
+
+// workgroups of a queue-fed launch: enough to fill the chip at the kernel's occupancy, never more than tiles
+static int queue_grid(int ntiles) {
+  static const int per_cu = [] { const char* v = getenv("HBEGP_TILE_WGS_PER_CU"); return v ? std::max(1, atoi(v)) : 6; }();
+  return std::max(1, std::min(ntiles, 256 * per_cu));
 }
 
 template <typename T>
 void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s,
-                 const EvalPrologue* pro) {
-  const int nt = np / 64;
+                 int* queue, const EvalPrologue* pro) {
+  const int nt = np / 64, ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
-  const dim3 grid(nt * (nt + 1) / 2), block(256);
+  const dim3 grid(queue_grid(ntiles)), block(256);
   const EvalPrologue pr = pro ? *pro : EvalPrologue{};
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
-    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
-    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
-    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
+    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
+    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
+    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
   }
 }
-template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t, const EvalPrologue*);
-template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t, const EvalPrologue*);
+template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t, int*, const EvalPrologue*);
+template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t, int*, const EvalPrologue*);
 
 // =================================================================================================================
 // alpha = K^-1 y through the explicit inverse factor: w = X y, alpha = X^T w;  lml pieces (lml.rs:54-59)
@@ -1226,54 +1271,114 @@ __device__ __forceinline__ bool last_workgroup(int* ticket) {
   if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return last;
 }
+// The same for a queue-fed launch: the ticket counts finished TILES (this workgroup hands in `mine` of `total`), so a workgroup
+// that found the queue empty takes no part.  Call with mine > 0, by the whole workgroup, every publishing wave drained.
+__device__ __forceinline__ bool last_of_tiles(int* ticket, int mine, int total) {
+  __shared__ int s_last_t;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int tk = __hip_atomic_fetch_add(ticket, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last_t = tk + mine == total;
+    if (s_last_t) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const bool last = s_last_t != 0;
+  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return last;
+}
 
-// one wave per row: w_i = sum_{k<=i} X[i][k] y[k]
+// w = X y (X lower triangular, row-major): w_i = sum_{k<=i} X[i][k] y[k]   (first half of alpha = X^T (X y), lml.rs:54)
+// Round 5: one wave takes TWO rows, i and np-1-i (together np+1 entries: every wave the same work -- with one wave per row the
+// launch ended with its longest rows), reads them with 16-byte loads, four independent loads in flight per lane (round 1-4:
+// one 8-byte load per lane per round trip, 92 % of the wave cycles in SQ_WAIT_ANY).  Fixed summation order: lane l adds the
+// entries k with (k / VEC) % 64 == l in ascending k into accumulator (k / (64 VEC)) % 4, then ((a0 + a1) + (a2 + a3)), then
+// the wave sum.  Entries above the diagonal are skipped by the k <= i test, not read as zeros.
 template <typename T>
 __global__ void __launch_bounds__(256) trmv_n_kernel(const T* __restrict__ Xinv, int np, int n, const T* __restrict__ y,
                                                      T* __restrict__ w, const int* info) {
   if (*info != 0) return;
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= np) return;
-  double acc = 0;
-  const T* xr = Xinv + (size_t)row * np;
-  // explicit fma: dag_trmv_n (dag_kernel.inc.hpp) repeats this sum and must round the same way wherever it is inlined
-  for (int k = lane; k <= row && k < n; k += 64) acc = __builtin_fma((double)xr[k], (double)y[k], acc);
-  acc = wave_sum(acc);
-  if (lane == 0) w[row] = (T)acc;
+  using C = Cfg<T>;
+  using vec_t = typename C::vec_t;
+  constexpr int VEC = C::VEC, SPAN = 64 * VEC;
+  const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (2 * gw >= np) return;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int row = half == 0 ? gw : np - 1 - gw;
+    if (half == 1 && row == gw) break;  // odd np: the middle row once
+    const T* xr = Xinv + (size_t)row * np;
+    const int len = min(row + 1, n);    // k <= row && k < n
+    double acc[4] = {0, 0, 0, 0};
+    for (int k0 = lane * VEC; k0 < len; k0 += 4 * SPAN) {
+      vec_t xv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * SPAN;
+        const bool in = k < len;  // a whole vector lies inside the row's padded storage: np is a multiple of 128 >= VEC
+        xv[u] = in ? *reinterpret_cast<const vec_t*>(xr + k) : vec_t{};
+        yv[u] = in ? *reinterpret_cast<const vec_t*>(y + k) : vec_t{};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (k0 + u * SPAN + e < len) acc[u] = __builtin_fma((double)xv[u][e], (double)yv[u][e], acc[u]);
+    }
+    double a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    a = wave_sum(a);
+    if (lane == 0) w[row] = (T)a;
+  }
 }
 
-// partial[chunk][j] = sum_{i in chunk, i>=j} X[i][j] w[i]; chunk = 256 rows; 64 columns per workgroup
+// partial[chunk][j] = sum_{i in chunk, i>=j} X[i][j] w[i]; chunk = 256 rows.  Round 5: a thread owns VEC adjacent columns
+// (16-byte loads: 64 lanes cover 128 columns in f64, 256 in f32), wave q of the four takes the rows i = q (mod 4); eight loads in
+// flight per lane.  Fixed order: per column the rows of a wave in ascending order, then the four waves' sums in order.
 template <typename T>
 __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv, int np, const T* __restrict__ w,
                                                      double* __restrict__ part, const int* info) {
   if (*info != 0) return;
-  __shared__ double red[4][64];
-  const int c = threadIdx.x & 63, sgrp = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c, chunk = blockIdx.y;
-  double acc = 0;
+  using C = Cfg<T>;
+  using vec_t = typename C::vec_t;
+  constexpr int VEC = C::VEC, COLS = 64 * VEC;
+  __shared__ double red[4][COLS];
+  const int lane = threadIdx.x & 63, sgrp = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * COLS, j0 = col0 + lane * VEC, chunk = blockIdx.y;
   const int i_begin = chunk * 256, i_end = min(i_begin + 256, np);
-  if (i_end > blockIdx.x * 64) {
-    // the same chain of fused multiply-adds in the same order (i ascending in steps of four); the loads of eight steps are
-    // issued together -- as a plain loop the compiler waited for each load before the next (17 us at n=256: 64 round trips)
+  if (i_end <= col0) return;  // the whole chunk lies above these columns' diagonal entries (uniform)
+  double acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0;
+  if (j0 < np) {
     int i = i_begin + sgrp;
     for (; i + 28 < i_end; i += 32) {
-      T xv[8], wv[8];
+      vec_t xv[8];
+      T wv[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int iu = i + 4 * u;
-        xv[u] = (iu >= j) ? Xinv[(size_t)iu * np + j] : T(0);
+        xv[u] = (iu >= j0) ? *reinterpret_cast<const vec_t*>(Xinv + (size_t)iu * np + j0) : vec_t{};
         wv[u] = w[iu];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i + 4 * u >= j) acc = __builtin_fma((double)xv[u], (double)wv[u], acc);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (i + 4 * u >= j0 + e) acc[e] = __builtin_fma((double)xv[u][e], (double)wv[u], acc[e]);
     }
-    for (; i < i_end; i += 4)
-      if (i >= j) acc = __builtin_fma((double)Xinv[(size_t)i * np + j], (double)w[i], acc);
+    for (; i < i_end; i += 4) {
+      if (i < j0) continue;
+      const vec_t xv = *reinterpret_cast<const vec_t*>(Xinv + (size_t)i * np + j0);
+      const double wi = (double)w[i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (i >= j0 + e) acc[e] = __builtin_fma((double)xv[e], wi, acc[e]);
+    }
   }
-  red[sgrp][c] = acc;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[sgrp][lane * VEC + e] = acc[e];
   __syncthreads();
-  if (sgrp == 0) part[(size_t)chunk * np + j] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  for (int c = threadIdx.x; c < COLS; c += 256)
+    if (col0 + c < np) part[(size_t)chunk * np + col0 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
 // lml = -1/2 y^T alpha - sum log L_ii - n/2 log(2 pi)   (lml.rs:57-59); fixed summation order; one thread
@@ -1301,7 +1406,17 @@ __global__ void __launch_bounds__(256) alpha_reduce_kernel(const double* __restr
   double ya = 0, ld = 0;
   if (j < np) {
     double a = 0;
-    for (int c = j / 256; c < nchunks; ++c) a += part[(size_t)c * np + j];
+    // same sum, chunk by chunk in ascending order; the loads of eight chunks are issued together (as a plain loop each one was
+    // waited for before the next: 16 dependent round trips at n = 4096)
+    int c = j / 256;
+    for (; c + 8 <= nchunks; c += 8) {
+      double pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pv[u] = part[(size_t)(c + u) * np + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += pv[u];
+    }
+    for (; c < nchunks; ++c) a += part[(size_t)c * np + j];
     const T at = (T)a;
     alpha[j] = (j < n) ? at : T(0);
     if (j < n) {
@@ -1328,9 +1443,10 @@ __global__ void lml_final_kernel(const double* __restrict__ sums, int nblocks, i
 template <typename T>
 void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, T* wbuf, double* part, T* alpha,
                       EvalOut* out, const int* info, hipStream_t s, int* ticket) {
-  hipLaunchKernelGGL((trmv_n_kernel<T>), dim3(np / 4), dim3(256), 0, s, Xinv, np, n, y, wbuf, info);
+  hipLaunchKernelGGL((trmv_n_kernel<T>), dim3((np / 2 + 3) / 4), dim3(256), 0, s, Xinv, np, n, y, wbuf, info);
   const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
-  hipLaunchKernelGGL((trmv_t_kernel<T>), dim3(np / 64, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info);
+  constexpr int TCOLS = 64 * Cfg<T>::VEC;
+  hipLaunchKernelGGL((trmv_t_kernel<T>), dim3((np + TCOLS - 1) / TCOLS, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info);
   // the per-workgroup sums live behind the chunk partials (part has room for nchunks*np + 2*np/256 doubles)
   double* sums = part + (size_t)nchunks * np;
   const int nblocks = (np + 255) / 256;
@@ -1350,31 +1466,41 @@ template void launch_alpha_lml<float>(const float*, int, int, const float*, cons
 // =================================================================================================================
 constexpr int GT_CHUNK = 8;  // length-scale parameters accumulated per register pass
 
+// Sums of NV per-thread values over the 256 threads of a workgroup, all at once: every thread parks its values in the LDS
+// ([v][256]), wave q adds up the values v = q, q + 4, ... (lane l: threads l, l + 64, l + 128, l + 192 in that order, then the
+// wave sum) and its lane 0 stores the result write-through.  Two barriers for up to GT_CHUNK + 2 values (round 1-4: a block sum
+// with two barriers per value -- 20 barriers per tile at d = 8, as much time as the tile's arithmetic).  Fixed order.
+template <int NV>
+__device__ __forceinline__ void block_sums_publish(const double (&v)[NV], int nv, double* red, double* dst) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __syncthreads();  // the previous use of red has been read
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+    if (q < nv) red[q * 256 + t] = v[q];
+  __syncthreads();
+  for (int q = wave; q < nv; q += 4) {
+    const double* r = red + q * 256;
+    double a = ((r[lane] + r[lane + 64]) + r[lane + 128]) + r[lane + 192];
+    a = wave_sum(a);
+    if (lane == 0) publish_f64(&dst[q], a);
+  }
+}
+
 template <typename T, int NU2>
-__device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, int d, int np,
-                                               const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
-                                               const T* __restrict__ alpha, double* __restrict__ part) {
-  extern __shared__ __align__(16) char smem_raw[];
-  T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] raw features of the i tile
-  T* xj = xi + (size_t)d * 64;
-  __shared__ double red[4];
-  __shared__ double inv_l2[MAXD];
-  const int li = tri_row(blockIdx.x), lj = blockIdx.x - li * (li + 1) / 2;
+__device__ __forceinline__ void gradtrace_tile(int tile, const T* __restrict__ X, int n, int d, int np, T amp, T noise,
+                                               const double* inv_l2, const T* __restrict__ Kinv, const T* __restrict__ alpha,
+                                               double* __restrict__ part, T* xi, T* xj, double* red) {
+  const int li = tri_row(tile), lj = tile - li * (li + 1) / 2;
   const int i0 = li * 64, j0 = lj * 64;
   const int t = threadIdx.x;
   for (int e = t; e < 64 * d; e += 256) {
     const int row = e / d, k = e - row * d;
     const int gi = i0 + row, gj = j0 + row;
     xi[k * 64 + row] = (gi < n) ? X[(size_t)gi * d + k] : T(0);
-    xj[k * 64 + row] = (gj < n) ? X[(size_t)gj * d + k] : T(0);
-  }
-  if (t < d) {
-    const T ell = (T)P->ell[t];
-    inv_l2[t] = (double)(T(1) / (ell * ell));  // 1/scales_k_square (matern_kernel.rs:94-98)
+    xj[xj_index<T>(k, row)] = (gj < n) ? X[(size_t)gj * d + k] : T(0);
   }
   __syncthreads();
   const int tx = t & 15, ty = t >> 4;
-  const T amp = (T)P->amp, noise = (T)P->noise;
 
   // pass A: per-element coefficient coef = wgt * W * c * g(r) and the noise / amplitude sums
   T coef[4][4];
@@ -1390,8 +1516,7 @@ __device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, i
       T a[4], b[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+      read_xj4<T>(xj, k, tx, b);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1426,14 +1551,19 @@ __device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, i
     if (li > lj && i0 + 64 <= n) {
       // a tile strictly below the diagonal and wholly inside the matrix: every entry counts twice, no bounds tests
       const vec4 aj = *reinterpret_cast<const vec4*>(alpha + j0 + tx * 4);
+      vec4 kv[4];
+      T ai[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // the four rows' loads together
+        const int gi = i0 + ty + 16 * r;
+        ai[r] = alpha[gi];
+        kv[r] = *reinterpret_cast<const vec4*>(Kinv + (size_t)gi * np + j0 + tx * 4);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = i0 + ty + 16 * r;
-        const T ai = alpha[gi];
-        const vec4 kv = *reinterpret_cast<const vec4*>(Kinv + (size_t)gi * np + j0 + tx * 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const T w = ai * aj[c] - kv[c];  // lml.rs:62 (tmp)
+          const T w = ai[r] * aj[c] - kv[r][c];  // lml.rs:62 (tmp)
           T km, gr;
           km_gr(dsum[r][c], &km, &gr);
           g_amp += (double)(T(2) * w * (amp * km));  // constant_kernel.rs:31-38 x K_matern
@@ -1464,20 +1594,14 @@ __device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, i
     }
   }
   const int p = d + 2;
-  double* my = part + (size_t)blockIdx.x * p;
-  {
-    const double s0 = block_sum(g_noise, red);
-    const double s1 = block_sum(g_amp, red);
-    if (t == 0) {
-      publish_f64(&my[0], s0);
-      publish_f64(&my[1], s1);
-    }
-  }
-  // pass B: length-scale gradients, GT_CHUNK parameters at a time
+  double* my = part + (size_t)tile * p;
+  // pass B: length-scale gradients, GT_CHUNK parameters at a time; the first chunk carries the noise / amplitude sums along
   for (int kc = 0; kc < d; kc += GT_CHUNK) {
-    double acc[GT_CHUNK];
+    double vals[GT_CHUNK + 2];
 #pragma unroll
-    for (int u = 0; u < GT_CHUNK; ++u) acc[u] = 0;
+    for (int u = 0; u < GT_CHUNK + 2; ++u) vals[u] = 0;
+    const int lead = kc == 0 ? 2 : 0;
+    if (kc == 0) { vals[0] = g_noise; vals[1] = g_amp; }
 #pragma unroll
     for (int u = 0; u < GT_CHUNK; ++u) {
       const int k = kc + u;
@@ -1486,8 +1610,7 @@ __device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, i
         T a[4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = xi[k * 64 + ty + 16 * r];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) b[c] = xj[k * 64 + tx * 4 + c];
+        read_xj4<T>(xj, k, tx, b);
         T sacc = T(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1496,17 +1619,12 @@ __device__ __forceinline__ void gradtrace_tile(const T* __restrict__ X, int n, i
             const T df = a[r] - b[c];
             sacc += coef[r][c] * (df * df * il2);
           }
-        acc[u] = (double)sacc;
+        if (kc == 0) vals[2 + u] = (double)sacc;
+        else vals[u] = (double)sacc;
       }
     }
-#pragma unroll
-    for (int u = 0; u < GT_CHUNK; ++u) {
-      const int k = kc + u;
-      if (k < d) {  // uniform
-        const double sres = block_sum(acc[u], red);
-        if (t == 0) publish_f64(&my[2 + k], sres);
-      }
-    }
+    const int nv = lead + min(GT_CHUNK, d - kc);
+    block_sums_publish<GT_CHUNK + 2>(vals, nv, red, my + (kc == 0 ? 0 : 2 + kc));
   }
 }
 
@@ -1552,16 +1670,42 @@ template <typename T, int NU2>
 __global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np,
                                                         const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
                                                         const T* __restrict__ alpha, double* __restrict__ part,
-                                                        const int* info, GradFinish fin) {
+                                                        const int* info, GradFinish fin, int* queue, int ntiles) {
+  extern __shared__ __align__(16) char smem_raw[];
+  T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] raw features of the i tile
+  T* xj = xi + (size_t)d * 64;             // j tile, xj_index layout
+  __shared__ double red[(GT_CHUNK + 2) * 256];
+  __shared__ double inv_l2[MAXD];
+  __shared__ int s_tile;
   const bool failed = *info != 0;
-  if (!fin.out) {
-    if (!failed) gradtrace_tile<T, NU2>(X, n, d, np, P, Kinv, alpha, part);
-    return;
-  }
-  if (!failed) gradtrace_tile<T, NU2>(X, n, d, np, P, Kinv, alpha, part);
-  if (!last_workgroup(fin.ticket)) return;
+  const int t = threadIdx.x;
+  int mine = 0;  // tiles this workgroup has done (uniform)
   if (!failed) {
-    finalize_grad_in_block(part, (int)gridDim.x, d + 2, fin.out);
+    if (t < d) {
+      const T ell = (T)P->ell[t];
+      inv_l2[t] = (double)(T(1) / (ell * ell));  // 1/scales_k_square (matern_kernel.rs:94-98)
+    }
+    const T amp = (T)P->amp, noise = (T)P->noise;
+    for (;;) {
+      const int tile = next_tile(queue, ntiles, &s_tile);
+      if (tile < 0) break;
+      gradtrace_tile<T, NU2>(tile, X, n, d, np, amp, noise, inv_l2, Kinv, alpha, part, xi, xj, red);
+      ++mine;
+    }
+  }
+  if (!fin.out) return;
+  if (failed) {
+    // no tile ran: every workgroup hands in one ticket, the last one publishes the (failed) evaluation
+    if (!last_workgroup(fin.ticket)) return;
+  } else {
+    if (mine == 0) return;
+    // every publishing lane (lane 0 of each wave) has its stores in the L2 before thread 0 hands in the workgroup's tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!last_of_tiles(fin.ticket, mine, ntiles)) return;
+  }
+  if (!failed) {
+    finalize_grad_in_block(part, ntiles, d + 2, fin.out);
     if (threadIdx.x == 0) atomicOr(&fin.out->done, 2);
   }
   __syncthreads();
@@ -1590,25 +1734,25 @@ size_t gradtrace_part_elems(int np, int d) {
 
 template <typename T>
 void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
-                      double* part, EvalOut* out, const int* info, hipStream_t s, int* ticket, EvalOut* hout) {
+                      double* part, EvalOut* out, const int* info, hipStream_t s, int* queue, int* ticket, EvalOut* hout) {
   const int nt = np / 64;
-  const int nblocks = nt * (nt + 1) / 2;
+  const int ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
-  const dim3 grid(nblocks), block(256);
+  const dim3 grid(queue_grid(ntiles)), block(256);
   GradFinish fin;
   if (ticket) { fin.out = out; fin.hout = hout; fin.ticket = ticket; }
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
-    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
-    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
-    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
+    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
+    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
+    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
   }
-  if (!ticket) hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, nblocks, d + 2, out, info);
+  if (!ticket) hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, ntiles, d + 2, out, info);
 }
 template void launch_gradtrace<double>(const double*, int, int, int, int, const EvalParams*, const double*, const double*,
-                                       double*, EvalOut*, const int*, hipStream_t, int*, EvalOut*);
+                                       double*, EvalOut*, const int*, hipStream_t, int*, int*, EvalOut*);
 template void launch_gradtrace<float>(const float*, int, int, int, int, const EvalParams*, const float*, const float*,
-                                      double*, EvalOut*, const int*, hipStream_t, int*, EvalOut*);
+                                      double*, EvalOut*, const int*, hipStream_t, int*, int*, EvalOut*);
 
 // =================================================================================================================
 // symmetrize: mirror the lower triangle into the upper one (what invc() hands back, lml.rs:62)
@@ -2629,6 +2773,15 @@ void init_kernels() {
   set_lds_attr(reinterpret_cast<const void*>(&leaf_kernel<double, float>), (int)LeafGeom<double>::LDS_BYTES, "leaf_kernel<f32>: dynamic LDS limit");
   init_dag_kernels();
   const int lb = 163840;
+  // kmat / gradtrace: 2 d 64 elements of dynamic LDS (64 KiB at d = 64 in f64) beside ~21 KiB of static LDS
+  {
+    const void* fns[] = {
+        (const void*)&kmat_kernel<double, 0>, (const void*)&kmat_kernel<double, 1>, (const void*)&kmat_kernel<double, 3>, (const void*)&kmat_kernel<double, 5>,
+        (const void*)&kmat_kernel<float, 0>, (const void*)&kmat_kernel<float, 1>, (const void*)&kmat_kernel<float, 3>, (const void*)&kmat_kernel<float, 5>,
+        (const void*)&gradtrace_kernel<double, 0>, (const void*)&gradtrace_kernel<double, 1>, (const void*)&gradtrace_kernel<double, 3>, (const void*)&gradtrace_kernel<double, 5>,
+        (const void*)&gradtrace_kernel<float, 0>, (const void*)&gradtrace_kernel<float, 1>, (const void*)&gradtrace_kernel<float, 3>, (const void*)&gradtrace_kernel<float, 5>};
+    for (const void* fn : fns) set_lds_attr(fn, 2 * MAXD * 64 * 8, "kmat / gradtrace kernel: dynamic LDS limit");
+  }
   set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 0>), lb, "small_eval_kernel: dynamic LDS limit");
   set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 1>), lb, "small_eval_kernel: dynamic LDS limit");
   set_lds_attr(reinterpret_cast<const void*>(&small_eval_kernel<double, 3>), lb, "small_eval_kernel: dynamic LDS limit");

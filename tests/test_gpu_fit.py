@@ -340,20 +340,28 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
                 assert tr["lml"][i] == -math.inf
             continue
         rf = []
+        kap = []
 
         def truth(kind, th=th, rf=rf):
             if not rf:
                 rf.append(PR.referee_for(X64, y64, th, bounds))
             return np.array([rf[0].lml()]) if kind == "lml" else rf[0].gradient()
 
+        def kappa(kind, th=th, kap=kap):
+            if not kap:
+                kap.append(PR.sigma32(X64, y64, th, bounds))
+            return kap[0][kind]
+
+        kl = (lambda: kappa("lml")) if dtype == np.float32 else None
+        kg = (lambda: kappa("grad")) if dtype == np.float32 else None
         if tr["lml"][i] == -math.inf:
             assert dtype == np.float32, (i, f)
             t_l = truth("lml")[0]
             assert abs(-f - t_l) > 1e-2 * max(1.0, abs(t_l)), (i, f, t_l)  # LAPACK f32's own answer is noise here
             n_gpu_only_failed += 1
         else:
-            judge.check(f"lml of evaluation {i}", [tr["lml"][i]], [-f], lambda: truth("lml"))
-            judge.check(f"gradient of evaluation {i}", tr["grad"][i], -g, lambda: truth("grad"))
+            judge.check(f"lml of evaluation {i}", [tr["lml"][i]], [-f], lambda: truth("lml"), sigma_fn=kl)
+            judge.check(f"gradient of evaluation {i}", tr["grad"][i], -g, lambda: truth("grad"), sigma_fn=kg)
         if rf:
             rf[0].close()
     print(f"persistent fit, every evaluation ({np.dtype(dtype).name}): " + judge.summary() +
@@ -366,8 +374,9 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
     if res is not None:  # (LAPACK f32 failing at the theta the engine captured: the reference has no digits there)
         rf = PR.referee_for(X64, y64, tr["theta"][i_best], bounds)
         jm = PR.Judge(tol)
-        jm.check("alpha of the fitted model", alpha, res["alpha"], lambda: sum(rf.alpha()))
-        jm.check("K^-1 of the fitted model", kinv, res["k_inv"], lambda: sum(rf.kinv()))
+        kb = PR.sigma32(X64, y64, tr["theta"][i_best], bounds) if dtype == np.float32 else None
+        jm.check("alpha of the fitted model", alpha, res["alpha"], lambda: sum(rf.alpha()), sigma_fn=(lambda: kb["alpha"]) if kb else None)
+        jm.check("K^-1 of the fitted model", kinv, res["k_inv"], lambda: sum(rf.kinv()), sigma_fn=(lambda: kb["kinv"]) if kb else None)
         print("fitted model: " + jm.summary())
         rf.close()
     mean, var, _ = fk.predict(X[:5])
