@@ -635,6 +635,23 @@ def main():
                                             "(evaluation + L-BFGS step on the device)")
         except Exception as e:
             out["small_n_side_line"] = {"error": str(e)}
+        if world == 1 and not args.no_side_lines:
+            # replicas on ONE GPU: k independent fits side by side, one host thread each, in a child
+            # process of its own so that GPU_MAX_HW_QUEUES (HIP's hardware queues per device: streams that share one run one after
+            # the other) can be raised there without touching this process
+            try:
+                conc = {}
+                for nn_, ks_ in ((128, "1 4 16"), (1024, "1 4")):
+                    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+                    cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "concurrent_fits.py"), str(nn_)] + ks_.split(),
+                                        env=env, capture_output=True, text=True, timeout=300)
+                    last = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                    conc[f"n={nn_}"] = json.loads(last[-1]) if last else {"error": (cp.stderr or cp.stdout)[-300:]}
+                out["concurrent_fits_side_line"] = dict(conc, note="aggregate fixed-work fits/s of k host threads fitting on one context / one GPU (config M "
+                                                        "data cut to n rows, 3 runs x 150 evaluations each), GPU_MAX_HW_QUEUES=16; every concurrent fit is "
+                                                        "compared bit for bit with the same fit alone")
+            except Exception as e:
+                out["concurrent_fits_side_line"] = {"error": str(e)}
         parity_failed = False
         if world == 1 and not args.no_cpu_baseline:
             par = {}

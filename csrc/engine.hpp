@@ -156,10 +156,9 @@ int dag_stage_depth(bool is_f32);  // contraction elements per pipeline stage of
 template <typename T>
 void launch_gemm(const GemmLaunch& g, int tile, hipStream_t s);  // tile in {32, 64, 128}
 
-// queue (kmat, gradtrace): a device int that is zero between launches -- the launch's tiles are dealt through it (kernels.hip)
 template <typename T>
 void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s,
-                 int* queue, const EvalPrologue* pro = nullptr);
+                 const EvalPrologue* pro = nullptr);
 
 // Factor the 128x128 diagonal block `blk` of W1 (lower) in place -> X_blk = L_blk^-1 into W2's block, diag(L) -> ldiag;
 // W3 (optional): the lower triangle of L_blk itself.
@@ -177,7 +176,7 @@ template <typename T>
 // ticket (device int, zero between launches): the launch's last workgroup finalises the gradient itself and, with hout, copies
 // the result block to the pinned one and publishes the evaluation's serial number -- no finalize / publish launches behind it
 void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
-                      double* part, EvalOut* out, const int* info, hipStream_t s, int* queue, int* ticket = nullptr, EvalOut* hout = nullptr);
+                      double* part, EvalOut* out, const int* info, hipStream_t s, int* ticket = nullptr, EvalOut* hout = nullptr);
 size_t gradtrace_part_elems(int np, int d);
 
 template <typename T>
@@ -224,6 +223,8 @@ struct LbfgsState;
 struct SmallFitResult {
   double best_lml;
   double best_theta[MAXP];   // as the optimiser passed it (log space, unclamped noise)
+  double best_params[MAXP];  // the clamped linear-space parameters the captured evaluation ran with (the DEVICE's exp of best_theta: the
+                             // model's L^-1 is refactored from exactly these, not from the host's exp of the same theta)
   int best_idx;              // ping-pong buffer (K^-1, alpha) that holds the captured evaluation; -1: every evaluation failed
   int best_eval;             // its index within the run
   int n_evals, n_not_pd;
@@ -244,8 +245,9 @@ struct SmallFit {
   double* trace_grad;        // [trace_cap][p]
   int trace_cap;
 };
+// fs_dev: device array of nruns descriptors; run r is workgroup r of one launch
 template <typename T>
-void launch_small_fit(const SmallFit& f, int nu2, hipStream_t s);
+void launch_small_fit(const SmallFit* fs_dev, int nruns, int nu2, hipStream_t s);
 
 void launch_set_info(int* info, int value, hipStream_t s);
 // start of an evaluation: info = n_warn = done = 0, lml and gradient poisoned with NaN (a launch that was rejected or

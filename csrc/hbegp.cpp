@@ -93,6 +93,20 @@ static std::atomic<int> g_live_ctx{0};  // the block pool is process-global: it 
 struct DevPool {
   std::mutex mu;
   std::map<std::pair<int, size_t>, std::vector<void*>> free_list;
+  // Fresh blocks are cleared on a NON-BLOCKING stream of the pool's own (one per device), never on the null stream: several
+  // host threads may be fitting on one context (hbegp.h: "re-entrant per ctx"), and any null-stream operation issued while
+  // another thread captures a graph fails with hipErrorStreamCaptureImplicit -- besides synchronising with nothing the engine
+  // runs on (its streams are non-blocking), which is how round 4's late clear came about.
+  std::map<int, hipStream_t> clear_stream;
+  hipStream_t stream_of(int dev) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = clear_stream.find(dev);
+    if (it != clear_stream.end()) return it->second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) throw HipError{hipErrorOutOfMemory, "hipStreamCreateWithFlags (pool)", __LINE__};
+    clear_stream[dev] = st;
+    return st;
+  }
   size_t cached = 0;
   static constexpr size_t MAX_CACHED = (size_t)24 << 30;
   void* get(int dev, size_t bytes, bool* fresh) {
@@ -127,7 +141,8 @@ struct DevPool {
     // or after, the block's first writer on such a stream (the model's copy of L^-1 in make_model, the kernel-matrix tiles of an
     // evaluation) and zeroes part or all of what was written -- seen once in round 4 as predictive variances that were off by
     // O(1) on a fresh process, where every block is a fresh one (profiles/r04_memset_race.txt).
-    const int delay_mb = getenv("HBEGP_POOL_NULL_DELAY_MB") ? atoi(getenv("HBEGP_POOL_NULL_DELAY_MB")) : 0;
+    // (the work matrices only: with every small array delayed as well the backlog on the null stream outlasts the whole test)
+    const int delay_mb = (bytes >= ((size_t)1 << 20) && getenv("HBEGP_POOL_NULL_DELAY_MB")) ? atoi(getenv("HBEGP_POOL_NULL_DELAY_MB")) : 0;
     if (delay_mb > 0) {
       static std::mutex dmu;
       static std::map<int, std::pair<void*, size_t>> scratch;  // per device, kept for the life of the process (a test switch)
@@ -141,11 +156,16 @@ struct DevPool {
       }
       if (sc.first) (void)hipMemsetAsync(sc.first, 0x5a, sc.second, nullptr);
     }
-    if (getenv("HBEGP_POOL_OLD_CLEAR") != nullptr && atoi(getenv("HBEGP_POOL_OLD_CLEAR")) != 0) {
+    if (bytes >= ((size_t)1 << 20) && getenv("HBEGP_POOL_OLD_CLEAR") != nullptr && atoi(getenv("HBEGP_POOL_OLD_CLEAR")) != 0) {
       e = hipMemset(p, 0, bytes);
-    } else {
+    } else if (delay_mb > 0) {
+      // the test's delayed form: the clear queues behind the long null-stream fill, and the synchronisation covers both
       e = hipMemsetAsync(p, 0, bytes, nullptr);
       if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    } else {
+      hipStream_t st = stream_of(dev);
+      e = hipMemsetAsync(p, 0, bytes, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e != hipSuccess) {
       (void)hipFree(p);
@@ -210,13 +230,19 @@ struct HostPool {
   }
 };
 static HostPool g_host_pool;
+// HIP maps its streams onto a few hardware queues per device (GPU_MAX_HW_QUEUES, default 4) in the order the streams are
+// created, and two streams that share a queue run one after the other.  So the pool is keyed by what a stream is FOR: the
+// evaluation slots of a fit always get the same streams back (created first, on distinct queues), whatever a model's or the
+// block pool's stream does in between -- with ONE free list a fit's three slots got, every other fit, two streams of one queue
+// (measured: optimiser runs of config M 561 / 900 / 561 / 900 ms).
+enum { STREAM_SLOT = 0, STREAM_MODEL = 1 };
 struct StreamPool {
   std::mutex mu;
-  std::map<int, std::vector<hipStream_t>> free_list;
-  hipStream_t get(int dev) {
+  std::map<std::pair<int, int>, std::vector<hipStream_t>> free_list;
+  hipStream_t get(int dev, int kind = STREAM_SLOT) {
     {
       std::lock_guard<std::mutex> lk(mu);
-      auto it = free_list.find(dev);
+      auto it = free_list.find({dev, kind});
       if (it != free_list.end() && !it->second.empty()) {
         hipStream_t s = it->second.back();
         it->second.pop_back();
@@ -228,10 +254,10 @@ struct StreamPool {
     if (e != hipSuccess) throw HipError{e, "hipStreamCreateWithFlags (pool)", __LINE__};
     return s;
   }
-  void put(int dev, hipStream_t s) {  // the caller has synchronised it
+  void put(int dev, hipStream_t s, int kind = STREAM_SLOT) {  // the caller has synchronised it
     if (!s) return;
     std::lock_guard<std::mutex> lk(mu);
-    auto& v = free_list[dev];
+    auto& v = free_list[{dev, kind}];
     if (v.size() >= 64) { (void)hipStreamDestroy(s); return; }
     v.push_back(s);
   }
@@ -387,6 +413,12 @@ static bool build_sched(const GemmLaunch& g, int tile, std::vector<int>* off, st
 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DAG_MAX_VARIANTS = 4;  // task-queue launches sized for 1..4 busy slots; with more slots the last one is shared
+// ... and, behind those, launch sizes for a CROWDED device: optimiser runs of OTHER fits in flight on the same GPU (several host
+// threads fitting side by side on one context -- replicas).  Sized for 6 / 12 / 24 runs in flight.
+constexpr int DAG_CROWD_LEVELS = 3;
+constexpr int DAG_CROWD_BUSY[DAG_CROWD_LEVELS] = {6, 12, 24};
+constexpr int MAX_DEVS = 64;
+static std::atomic<int> g_dev_busy[MAX_DEVS];  // optimiser runs in flight per device id, over all fits of the process
 
 template <typename T>
 struct Slot {
@@ -398,7 +430,7 @@ struct Slot {
   double *part_t = nullptr, *part_g = nullptr;
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
-  int* tickets = nullptr;    // [0] alpha / lml reduction, [1] gradient: "last workgroup finishes the launch's job" counters; [2] kernel-matrix, [3] gradient: tile queues (all zero between launches)
+  int* tickets = nullptr;    // [0] alpha / lml reduction, [1] gradient: "last workgroup finishes the launch's job" counters (zero between launches)
   unsigned long long* dag_trace = nullptr;  // HBEGP_DAG_TRACE: per-task time stamps of the last evaluation
   int* dag_ctrl = nullptr;   // queue head + dependency counters of the task-queue kernel (cleared before every launch)
   EvalParams* hP = nullptr;  // pinned
@@ -407,12 +439,13 @@ struct Slot {
   size_t small_slab_bytes = 0;
   void* host_slab = nullptr;    // one pooled pinned block behind hP, hOut
   size_t host_slab_bytes = 0;
-  hipGraphExec_t graph[DAG_MAX_VARIANTS + 1][2][2] = {};  // [task-queue variant][target][want_grad]
+  hipGraphExec_t graph[DAG_MAX_VARIANTS + 1 + DAG_CROWD_LEVELS][2][2] = {};  // [task-queue variant][target][want_grad]
   // capture state (fit.rs:116-125)
   int best_idx = -1;  // which ping-pong buffer holds the best evaluation so far
   double best_lml = -std::numeric_limits<double>::infinity();
   int best_run = 0, best_eval = 0;
   std::vector<double> best_theta;
+  std::vector<double> best_params;  // persistent fit kernel only: the clamped linear parameters the device evaluated the captured theta with
   int last_target = 0;  // buffer written by the most recent evaluation
   int dag_variant = 1;  // which ordering / launch size the next task-queue launch uses (Problem::DagVariant)
   T* dag_kinv = nullptr;  // K^-1 buffer the task-queue launch writes (its X^T X tiles); null: factorisation only
@@ -458,6 +491,7 @@ struct Problem : ProblemBase {
   std::vector<DagVariant> dag_var;          // [0] unused, [v] for v busy slots
   std::unique_ptr<std::atomic<int>[]> busy_slots_;  // per device: slots inside an optimiser run (0: not known -> all of them)
   int dag_ntasks = 0, dag_nwg = 0;          // dag_nwg: workgroups of the default variant (all slots busy)
+  int dag_nvar_ = 1, dag_ncrowd_ = 0;       // variants [1..dag_nvar_] for this fit's own busy slots, then dag_ncrowd_ crowded-device levels
   unsigned long long dag_wait_ticks_ = 200000000ull;  // bound of one dependency wait (100 MHz ticks), see init()
   size_t dag_ctrl_bytes = 0;
   double dag_gflop = 0;
@@ -482,6 +516,20 @@ struct Problem : ProblemBase {
   // every evaluation would then sit out wait_eval's two-second fallback, or silently fall back to hipStreamSynchronize)
   bool eval_published() const { return hostio_ && !small_; }
   int leaf_dbg_ = 0;                        // HBEGP_LEAF_DBG: debug bits of the diagonal-block kernel (16: helper waves start late)
+
+  // Small device arrays of the problem (features, targets, task queues, schedule tables, control words) come from the block
+  // pool too and go back to it in release(): hipMalloc / hipFree synchronise the whole device, which serialises host threads
+  // that fit side by side on one context (and cost ~2 ms of a 10 ms fit even alone).
+  struct Pooled { int dev; void* p; size_t bytes; };
+  std::vector<Pooled> pooled_;
+  template <typename U>
+  U* palloc(int dev, size_t count) {
+    bool fresh = false;
+    const size_t bytes = std::max<size_t>(16, sizeof(U) * count);
+    void* q = g_pool.get(dev, bytes, &fresh);
+    pooled_.push_back({dev, q, bytes});
+    return static_cast<U*>(q);
+  }
 
   // single_shot: the problem runs one evaluation (extend): skip the static schedule tables, every GEMM launch is ad hoc
   // like_fit: choose the evaluation path (launches / task queue) as a fit of this size does, whatever the slot count --
@@ -517,15 +565,20 @@ struct Problem : ProblemBase {
     slots.resize(c->devs.size());
     for (size_t di = 0; di < c->devs.size(); ++di) {
       HIPCHECK(hipSetDevice(c->devs[di]));
-      HIPCHECK(hipMalloc(&Xd[di], sizeof(T) * (size_t)n * d));
-      HIPCHECK(hipMalloc(&yd[di], sizeof(T) * np));
-      HIPCHECK(hipMemset(yd[di], 0, sizeof(T) * np));
-      HIPCHECK(hipMemcpy(Xd[di], X, sizeof(T) * (size_t)n * d, hipMemcpyHostToDevice));
-      HIPCHECK(hipMemcpy(yd[di], y, sizeof(T) * n, hipMemcpyHostToDevice));
       slots[di].resize(n_slots);
       for (auto& s : slots[di]) {
         s.dev = c->devs[di];
         s.stream = g_stream_pool.get(s.dev);
+      }
+      // everything this constructor queues goes to the first slot's (non-blocking) stream and is waited for on THAT stream:
+      // no null-stream operation, no device-wide synchronisation (other host threads may be fitting on this device)
+      hipStream_t st0 = slots[di][0].stream;
+      Xd[di] = palloc<T>(c->devs[di], (size_t)n * d);
+      yd[di] = palloc<T>(c->devs[di], np);
+      HIPCHECK(hipMemsetAsync(yd[di], 0, sizeof(T) * np, st0));
+      HIPCHECK(hipMemcpyAsync(Xd[di], X, sizeof(T) * (size_t)n * d, hipMemcpyHostToDevice, st0));
+      HIPCHECK(hipMemcpyAsync(yd[di], y, sizeof(T) * n, hipMemcpyHostToDevice, st0));
+      for (auto& s : slots[di]) {
         bool fresh1 = false, fresh2 = false, fk = false;
         s.W1 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh1));
         s.W2 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &fresh2));
@@ -534,11 +587,11 @@ struct Problem : ProblemBase {
         // BE zero (tiles on the diagonal are loaded whole).  Nothing in the engine writes there, so clearing the buffer
         // once per slot is enough -- also when it is recycled from the pool (it may have held a full symmetric K^-1).
         // W1's strict upper part is only ever multiplied by those zeros or ignored: it just has to be finite.
-        HIPCHECK(hipMemsetAsync(s.W2, 0, sizeof(T) * nn, nullptr));
+        HIPCHECK(hipMemsetAsync(s.W2, 0, sizeof(T) * nn, st0));
         if (refine_) {
           bool f3 = false;
           s.W3 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &f3));
-          HIPCHECK(hipMemsetAsync(s.W3, 0, sizeof(T) * nn, nullptr));  // strict upper triangle must be zero, like W2's
+          HIPCHECK(hipMemsetAsync(s.W3, 0, sizeof(T) * nn, st0));  // strict upper triangle must be zero, like W2's
         }
         (void)fresh1; (void)fresh2; (void)fk;  // fresh blocks were cleared by the pool
         // the small per-slot arrays: one pooled block
@@ -561,8 +614,8 @@ struct Problem : ProblemBase {
           s.dP = reinterpret_cast<EvalParams*>(q); q += b_p;
           s.dOut = reinterpret_cast<EvalOut*>(q); q += b_o;
           s.tickets = reinterpret_cast<int*>(q);
-          HIPCHECK(hipMemsetAsync(s.dOut, 0, sizeof(EvalOut), nullptr));
-          HIPCHECK(hipMemsetAsync(s.tickets, 0, 256, nullptr));
+          HIPCHECK(hipMemsetAsync(s.dOut, 0, sizeof(EvalOut), st0));
+          HIPCHECK(hipMemsetAsync(s.tickets, 0, 256, st0));
           const size_t h_p = up(sizeof(EvalParams));
           s.host_slab_bytes = h_p + up(sizeof(EvalOut));
           s.host_slab = g_host_pool.get(s.host_slab_bytes);
@@ -572,7 +625,7 @@ struct Problem : ProblemBase {
           memset(s.hOut, 0, sizeof(EvalOut));
         }
       }
-      HIPCHECK(hipDeviceSynchronize());
+      HIPCHECK(hipStreamSynchronize(st0));
     }
     // Task queue of the factorisation.  The workgroups of one launch hold a CU each while they wait for the diagonal
     // blocks, so a problem whose slots run concurrently shares the CUs between its slots.
@@ -702,14 +755,20 @@ struct Problem : ProblemBase {
         busy_slots_.reset(new std::atomic<int>[c->devs.size()]);
         for (size_t di = 0; di < c->devs.size(); ++di) busy_slots_[di].store(0);
         // the variants: [nvar] = the default (every slot busy), [v < nvar] for v busy slots (HBEGP_DAG_ADAPT=0: default only)
-        dag_var.assign(nvar + 1, DagVariant());
         const bool adapt = env_int("HBEGP_DAG_ADAPT", 1) != 0 && forced <= 0;
-        for (int v = 1; v <= nvar; ++v) {
+        // [nvar + 1 + l]: a crowded device, DAG_CROWD_BUSY[l] runs in flight over all fits (only for problems with several slots: a fit;
+        // same tasks, same bits -- fewer workgroups per launch, so that all the launches in flight are resident)
+        dag_nvar_ = nvar;
+        dag_ncrowd_ = (adapt && n_slots > 1) ? DAG_CROWD_LEVELS : 0;
+        dag_var.assign(nvar + 1 + dag_ncrowd_, DagVariant());
+        for (int v = 1; v <= nvar + dag_ncrowd_; ++v) {
           DagVariant& var = dag_var[v];
           std::shared_ptr<const DagPlan> pv = cached;
           var.nwg = dag_nwg;
-          if (v < nvar && adapt) {
-            var.nwg = std::min(share_of(v), dag_ntasks);
+          if (v != nvar && adapt) {
+            const int busy = v < nvar ? v : DAG_CROWD_BUSY[v - nvar - 1];
+            var.nwg = std::min(share_of(busy), dag_ntasks);
+            if (v > nvar) var.nwg = std::min(var.nwg, dag_nwg);
             pv = plan_for(var.nwg);
             if (pv->tasks.size() != plan.tasks.size()) { pv = cached; var.nwg = dag_nwg; }  // cannot happen: same task set
           }
@@ -717,8 +776,8 @@ struct Problem : ProblemBase {
           var.tasks.assign(c->devs.size(), nullptr);
           for (size_t di = 0; di < c->devs.size(); ++di) {
             HIPCHECK(hipSetDevice(c->devs[di]));
-            HIPCHECK(hipMalloc(&var.tasks[di], sizeof(DagTask) * pv->tasks.size()));
-            HIPCHECK(hipMemcpy(var.tasks[di], pv->tasks.data(), sizeof(DagTask) * pv->tasks.size(), hipMemcpyHostToDevice));
+            var.tasks[di] = palloc<DagTask>(c->devs[di], pv->tasks.size());
+            HIPCHECK(hipMemcpyAsync(var.tasks[di], var.host_tasks.data(), sizeof(DagTask) * var.host_tasks.size(), hipMemcpyHostToDevice, slots[di][0].stream));  // (the source outlives the copy: it is the problem's own)
           }
         }
         for (size_t di = 0; di < c->devs.size(); ++di) {
@@ -728,14 +787,14 @@ struct Problem : ProblemBase {
               bool f3 = false;
               s.W3 = static_cast<T*>(g_pool.get(s.dev, sizeof(T) * nn, &f3));  // the factor L: every tile read has been written
             }
-            HIPCHECK(hipMalloc(&s.dag_ctrl, dag_ctrl_bytes));
-            HIPCHECK(hipMemset(s.dag_ctrl, 0, dag_ctrl_bytes));
+            s.dag_ctrl = palloc<int>(s.dev, dag_ctrl_bytes / sizeof(int));
+            HIPCHECK(hipMemsetAsync(s.dag_ctrl, 0, dag_ctrl_bytes, slots[di][0].stream));
             if (getenv("HBEGP_DAG_TRACE")) {
-              HIPCHECK(hipMalloc(&s.dag_trace, sizeof(unsigned long long) * 5 * plan.tasks.size()));
-              HIPCHECK(hipMemset(s.dag_trace, 0, sizeof(unsigned long long) * 5 * plan.tasks.size()));
+              s.dag_trace = palloc<unsigned long long>(s.dev, 5 * plan.tasks.size());
+              HIPCHECK(hipMemsetAsync(s.dag_trace, 0, sizeof(unsigned long long) * 5 * plan.tasks.size(), slots[di][0].stream));
             }
           }
-          HIPCHECK(hipStreamSynchronize(nullptr));  // the fills above are queued on the null stream; the slot streams do not wait for it
+          HIPCHECK(hipStreamSynchronize(slots[di][0].stream));  // the copies and fills above; the other slots' streams do not wait for this one
         }
       }
     }
@@ -756,7 +815,7 @@ struct Problem : ProblemBase {
       (void)hipSetDevice(ctx->devs[di]);
       for (auto& s : slots[di]) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
-        for (int v = 0; v <= DAG_MAX_VARIANTS; ++v)
+        for (int v = 0; v <= DAG_MAX_VARIANTS + DAG_CROWD_LEVELS; ++v)
           for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 2; ++b)
               if (s.graph[v][a][b]) (void)hipGraphExecDestroy(s.graph[v][a][b]);
@@ -765,15 +824,11 @@ struct Problem : ProblemBase {
         for (int b = 0; b < 2; ++b) g_pool.put(s.dev, s.Kinv[b], nnb);
         g_pool.put(s.dev, s.small_slab, s.small_slab_bytes);
         g_host_pool.put(s.host_slab, s.host_slab_bytes);
-        (void)hipFree(s.dag_ctrl); (void)hipFree(s.dag_trace);
         g_stream_pool.put(s.dev, s.stream);  // synchronised above
       }
-      (void)hipFree(Xd[di]); (void)hipFree(yd[di]);
-      for (auto& var : dag_var)
-        if (di < var.tasks.size()) (void)hipFree(var.tasks[di]);
-      if (di < scheds.size())
-        for (auto& sc : scheds[di]) { (void)hipFree(sc.d_off); (void)hipFree(sc.d_items); }
     }
+    for (const Pooled& q : pooled_) g_pool.put(q.dev, q.p, q.bytes);  // features, targets, task queues, control words, schedule tables
+    pooled_.clear();
     slots.clear();
     scheds.clear();
     dag_var.clear();
@@ -798,10 +853,11 @@ struct Problem : ProblemBase {
       int nwg = 0;
       if (build_sched(g, sc.tile, &off, &items, &nwg)) {
         sc.nwg = nwg;
-        HIPCHECK(hipMalloc(&sc.d_off, sizeof(int) * off.size()));
-        HIPCHECK(hipMalloc(&sc.d_items, sizeof(unsigned) * items.size()));
-        HIPCHECK(hipMemcpy(sc.d_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice));
-        HIPCHECK(hipMemcpy(sc.d_items, items.data(), sizeof(unsigned) * items.size(), hipMemcpyHostToDevice));
+        sc.d_off = palloc<int>(s.dev, off.size());
+        sc.d_items = palloc<unsigned>(s.dev, items.size());
+        HIPCHECK(hipMemcpyAsync(sc.d_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, stream));
+        HIPCHECK(hipMemcpyAsync(sc.d_items, items.data(), sizeof(unsigned) * items.size(), hipMemcpyHostToDevice, stream));
+        HIPCHECK(hipStreamSynchronize(stream));  // off / items are locals
       }
       if ((int)scheds[di].size() <= ord) scheds[di].resize(ord + 1);
       scheds[di][ord] = sc;
@@ -914,7 +970,7 @@ struct Problem : ProblemBase {
   void dag_report_timeout(Slot<T>& s) {
     if (!s.dag_ctrl) return;
     std::vector<int> ctrl(dag_ctrl_bytes / sizeof(int));
-    if (hipMemcpy(ctrl.data(), s.dag_ctrl, dag_ctrl_bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (hipMemcpyAsync(ctrl.data(), s.dag_ctrl, dag_ctrl_bytes, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipStreamSynchronize(s.stream) != hipSuccess) return;
     const int row = ctrl[1] - 1;
     fprintf(stderr, "task queue timeout: queue head %d of %d, first task that gave up: %d\n", ctrl[0], dag_ntasks, row);
     const std::vector<DagTask>& host_tasks = dag_var[s.dag_variant].host_tasks;
@@ -1053,13 +1109,13 @@ struct Problem : ProblemBase {
           s.ctrl_cleared = true;
         }
         if (tm) tm->begin(PhaseTimer::KMAT);
-        launch_kmat<T>(Xd[di], n, d, np, nu2, s.hP, s.W1, info, s.stream, s.tickets + 2, &pro);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.hP, s.W1, info, s.stream, &pro);
         if (tm) tm->end();
       } else {
         HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
         launch_reset_out(s.dOut, s.stream);
         if (tm) tm->begin(PhaseTimer::KMAT);
-        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream, s.tickets + 2);
+        launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
         if (tm) tm->end();
       }
     }
@@ -1086,13 +1142,12 @@ struct Problem : ProblemBase {
     bool fuse_grad = false;
     if (want_grad) {
       if (tm) tm->begin(PhaseTimer::GRAD);
-      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation.  Since round 5 the launch is
-      // queue-fed: a workgroup drains its write-through partials ONCE, when it has run out of tiles, and workgroups that found
-      // the queue empty take no part (round 4: one drain per tile-workgroup -- 2,080 at n = 4096 -- made the fused form slower
-      // there: 138 -> 182 us inside a fit, so it was limited to 512 tiles).  HBEGP_FUSE_GRAD_MAX_TILES overrides.
-      static const int fuse_max = env_int("HBEGP_FUSE_GRAD_MAX_TILES", 1 << 30);
-      fuse_grad = hostio && (np / 64) * (np / 64 + 1) / 2 <= fuse_max;
-      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream, s.tickets + 3,
+      // hostio: the launch's last workgroup also finalises the gradient and publishes the evaluation -- where the launch is a
+      // few hundred workgroups (latency-bound sizes).  Every workgroup drains its write-through partials before it takes its
+      // ticket (~2 us at the end of its life): with the 2,080 workgroups of n = 4096 queueing for the ~60 CUs the other two
+      // task-queue launches leave free that made the launch 138 -> 182 us; there the two tiny launches behind it are free.
+      fuse_grad = hostio && (np / 64) * (np / 64 + 1) / 2 <= 512;
+      launch_gradtrace<T>(Xd[di], n, d, np, nu2, s.dP, s.Kinv[target], s.alpha[target], s.part_g, s.dOut, info, s.stream,
                           fuse_grad ? s.tickets + 1 : nullptr, fuse_grad ? s.hOut : nullptr);
       if (tm) tm->end();
     }
@@ -1150,7 +1205,8 @@ struct Problem : ProblemBase {
   }
 
   // Kernel matrix + Cholesky/inverse-factor recursion only (no alpha, no K^-1): leaves X = L^-1 in the slot's W2.
-  // Used when a model is built: X of the captured theta is recomputed (bitwise the same arithmetic as in the evaluation).
+  // Used when a model is built: X of the captured theta is recomputed (bitwise the same arithmetic as in the evaluation, from the
+  // same parameters: a device-driven fit hands over the numbers its evaluation ran with, SmallFitResult::best_params).
   int factor_only(size_t di, int si) {
     Slot<T>& s = slots[di][si];
     HIPCHECK(hipSetDevice(s.dev));
@@ -1165,7 +1221,7 @@ struct Problem : ProblemBase {
       HIPCHECK(hipStreamSynchronize(s.stream));
       return s.hOut->info != 0 ? HBEGP_NOT_PD : HBEGP_OK;
     }
-    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream, s.tickets + 2);
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, &s.dOut->info, s.stream);
     chol_inv(s, di, np / NB, nullptr);
     CHECK_LAUNCHES();
     HIPCHECK(hipMemcpyAsync(s.hOut, s.dOut, sizeof(EvalOut), hipMemcpyDeviceToHost, s.stream));
@@ -1204,7 +1260,7 @@ struct Problem : ProblemBase {
     HIPCHECK(hipMemcpy2DAsync(s.W2, sizeof(T) * np, pXinv, sizeof(T) * pnp, sizeof(T) * w, w, hipMemcpyDeviceToDevice, s.stream));
     HIPCHECK(hipMemcpy2DAsync(s.Kinv[0], sizeof(T) * np, pKinv, sizeof(T) * pnp, sizeof(T) * w, w, hipMemcpyDeviceToDevice, s.stream));
     HIPCHECK(hipMemcpyAsync(s.ldiag, pldiag, sizeof(T) * w, hipMemcpyDeviceToDevice, s.stream));
-    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream, s.tickets + 2);
+    launch_kmat<T>(Xd[di], n, d, np, nu2, s.dP, s.W1, info, s.stream);
     const bool was_adhoc = adhoc_;
     adhoc_ = true;
     try {
@@ -1253,8 +1309,18 @@ struct Problem : ProblemBase {
   // run at this moment (a fit keeps the count; outside a fit every slot is assumed busy).
   int variant_now(size_t di) const {
     if (!dag_ || dag_var.size() < 2) return 1;
-    const int nvar = (int)dag_var.size() - 1;
+    const int nvar = dag_nvar_;
     const int busy = busy_slots_ ? busy_slots_[di].load(std::memory_order_relaxed) : 0;
+    if (dag_ncrowd_ > 0) {
+      // runs in flight on this GPU over ALL fits of the process: beyond what this fit alone accounts for, the device is crowded
+      const int dev = ctx->devs[di];
+      const int total = dev < MAX_DEVS ? g_dev_busy[dev].load(std::memory_order_relaxed) : 0;
+      if (total > std::max(busy, nvar)) {
+        int l = 0;
+        while (l + 1 < dag_ncrowd_ && DAG_CROWD_BUSY[l] < total) ++l;
+        return nvar + 1 + l;
+      }
+    }
     return busy <= 0 ? nvar : std::min(busy, nvar);
   }
   // Run one evaluation on (device index di, slot si) into ping-pong buffer `target`; blocks until the result is on the host.
@@ -1408,7 +1474,8 @@ struct Problem : ProblemBase {
       HIPCHECK(hipStreamSynchronize(s.stream));
       const std::vector<DagTask>& dag_host_tasks = dag_var[s.dag_variant].host_tasks;
       std::vector<unsigned long long> tr((size_t)5 * dag_ntasks);
-      HIPCHECK(hipMemcpy(tr.data(), s.dag_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost));
+      HIPCHECK(hipMemcpyAsync(tr.data(), s.dag_trace, sizeof(unsigned long long) * tr.size(), hipMemcpyDeviceToHost, s.stream));
+      HIPCHECK(hipStreamSynchronize(s.stream));
       if (FILE* f = fopen(getenv("HBEGP_DAG_TRACE"), "w")) {
         for (int i = 0; i < dag_ntasks; ++i) {
           const DagTask& t = dag_host_tasks[i];
@@ -1527,40 +1594,68 @@ struct hbegp_model {
   void *sm_Xs = nullptr, *sm_Ks = nullptr, *sm_out = nullptr, *sm_hin = nullptr, *sm_hout = nullptr;
   double *sm_pmean = nullptr, *sm_w = nullptr;
   std::mutex mu;
+  // every device array of the model comes from the block pool and goes back to it (no hipMalloc / hipFree on the caller's
+  // path: they synchronise the whole device, i.e. every other host thread's fit); pinned blocks and the stream likewise
+  struct Pooled { void* p; size_t bytes; };
+  std::vector<Pooled> pooled;
+  size_t sm_hin_bytes = 0, sm_hout_bytes = 0;
+  void* palloc(size_t bytes) {
+    bool fresh = false;
+    bytes = std::max<size_t>(16, bytes);
+    void* q = g_pool.get(dev, bytes, &fresh);
+    pooled.push_back({q, bytes});
+    return q;
+  }
+  void pfree(void* q) {
+    for (size_t i = 0; i < pooled.size(); ++i)
+      if (pooled[i].p == q) {
+        g_pool.put(dev, q, pooled[i].bytes);
+        pooled.erase(pooled.begin() + (long)i);
+        return;
+      }
+  }
   ~hbegp_model() {
     (void)hipSetDevice(dev);
     if (stream) (void)hipStreamSynchronize(stream);
-    (void)hipFree(X); (void)hipFree(alpha); (void)hipFree(ldiag); g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes); (void)hipFree(dP); (void)hipFree(dOut);
-    (void)hipFree(Xs); (void)hipFree(Ks); (void)hipFree(Q); (void)hipFree(mean); (void)hipFree(var);
-    (void)hipFree(sm_Xs); (void)hipFree(sm_Ks); (void)hipFree(sm_out); (void)hipFree(sm_pmean); (void)hipFree(sm_w);
-    (void)hipHostFree(sm_hin); (void)hipHostFree(sm_hout);
-    if (stream) (void)hipStreamDestroy(stream);
+    g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes);
+    for (const Pooled& q : pooled) g_pool.put(dev, q.p, q.bytes);
+    g_host_pool.put(sm_hin, sm_hin_bytes); g_host_pool.put(sm_hout, sm_hout_bytes);
+    g_stream_pool.put(dev, stream, STREAM_MODEL);  // synchronised above
   }
 };
 
 template <typename T>
 static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double* theta_clamped, double lml,
-                               bool w2_current = false) {
+                               bool w2_current = false, const double* params_linear = nullptr) {
   Slot<T>& s = prob.slots[di][si];
   HIPCHECK(hipSetDevice(s.dev));
   std::unique_ptr<hbegp_model> m(new hbegp_model());
   m->dev = s.dev; m->n = prob.n; m->d = prob.d; m->np = prob.np; m->nu2 = prob.nu2; m->is_f32 = prob.is_f32; m->lml = lml;
   m->theta.assign(theta_clamped, theta_clamped + prob.d + 2);
   const size_t nn = (size_t)prob.np * prob.np;
-  HIPCHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-  HIPCHECK(hipMalloc(&m->X, sizeof(T) * (size_t)prob.n * prob.d));
-  HIPCHECK(hipMalloc(&m->alpha, sizeof(T) * prob.np));
+  m->stream = g_stream_pool.get(m->dev, STREAM_MODEL);
+  m->X = m->palloc(sizeof(T) * (size_t)prob.n * prob.d);
+  m->alpha = m->palloc(sizeof(T) * prob.np);
   { bool fr; m->Kinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->Xinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->kinv_bytes = sizeof(T) * nn; }
-  HIPCHECK(hipMalloc(&m->dP, sizeof(EvalParams)));
-  HIPCHECK(hipMalloc(&m->dOut, sizeof(EvalOut)));
+  m->dP = static_cast<EvalParams*>(m->palloc(sizeof(EvalParams)));
+  m->dOut = static_cast<EvalOut*>(m->palloc(sizeof(EvalOut)));
   const int b = s.best_idx < 0 ? s.last_target : s.best_idx;
   // X = L^-1 at the model's theta (the evaluation slots only keep K^-1 and alpha of the captured evaluation)
   // (w2_current: the slot's last evaluation WAS at this theta -- extend -- so W2 and ldiag already hold them)
+  auto fill_params = [&](EvalParams* P) {
+    if (params_linear) {  // a device-driven fit: the very numbers the captured evaluation ran with
+      P->noise = params_linear[0];
+      P->amp = params_linear[1];
+      for (int k = 0; k < prob.d; ++k) P->ell[k] = params_linear[2 + k];
+    } else {
+      theta_to_params(theta_clamped, nullptr, nullptr, prob.d, P);
+    }
+  };
   if (!w2_current) {
-    theta_to_params(theta_clamped, nullptr, nullptr, prob.d, s.hP);
+    fill_params(s.hP);
     if (prob.factor_only(di, si) != HBEGP_OK) throw HipError{hipErrorUnknown, "factorisation at the captured theta failed", __LINE__};
   }
-  HIPCHECK(hipMalloc(&m->ldiag, sizeof(T) * prob.np));
+  m->ldiag = m->palloc(sizeof(T) * prob.np);
   HIPCHECK(hipMemcpyAsync(m->ldiag, s.ldiag, sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->Xinv, s.W2, sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->X, prob.Xd[di], sizeof(T) * (size_t)prob.n * prob.d, hipMemcpyDeviceToDevice, m->stream));
@@ -1570,7 +1665,7 @@ static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double
   CHECK_LAUNCHES();
   EvalParams P;
   memset(&P, 0, sizeof(P));
-  theta_to_params(theta_clamped, nullptr, nullptr, prob.d, &P);
+  fill_params(&P);
   HIPCHECK(hipMemcpyAsync(m->dP, &P, sizeof(P), hipMemcpyHostToDevice, m->stream));
   HIPCHECK(hipStreamSynchronize(m->stream));
   return m.release();
@@ -1587,13 +1682,15 @@ static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, 
     // a handful of candidates (the caller's scalar predict_* loops): read L^-1 once instead of a padded 128-row tile GEMM
     const size_t out_bytes = sizeof(T) * 2 * PRED_SMALL_MAX + 16;
     if (!m->sm_Xs) {
-      HIPCHECK(hipMalloc(&m->sm_Xs, sizeof(T) * PRED_SMALL_MAX * m->d));
-      HIPCHECK(hipMalloc(&m->sm_Ks, sizeof(T) * (size_t)PRED_SMALL_MAX * m->np));
-      HIPCHECK(hipMalloc(&m->sm_out, out_bytes));
-      HIPCHECK(hipMalloc(&m->sm_pmean, sizeof(double) * (size_t)((m->np + 255) / 256) * PRED_SMALL_MAX));
-      HIPCHECK(hipMalloc(&m->sm_w, sizeof(double) * (size_t)m->n * PRED_SMALL_MAX));
-      HIPCHECK(hipHostMalloc(&m->sm_hin, sizeof(T) * PRED_SMALL_MAX * m->d, hipHostMallocDefault));
-      HIPCHECK(hipHostMalloc(&m->sm_hout, out_bytes, hipHostMallocDefault));
+      m->sm_Xs = m->palloc(sizeof(T) * PRED_SMALL_MAX * m->d);
+      m->sm_Ks = m->palloc(sizeof(T) * (size_t)PRED_SMALL_MAX * m->np);
+      m->sm_out = m->palloc(out_bytes);
+      m->sm_pmean = static_cast<double*>(m->palloc(sizeof(double) * (size_t)((m->np + 255) / 256) * PRED_SMALL_MAX));
+      m->sm_w = static_cast<double*>(m->palloc(sizeof(double) * (size_t)m->n * PRED_SMALL_MAX));
+      m->sm_hin_bytes = sizeof(T) * PRED_SMALL_MAX * m->d;
+      m->sm_hout_bytes = out_bytes;
+      m->sm_hin = g_host_pool.get(m->sm_hin_bytes);
+      m->sm_hout = g_host_pool.get(m->sm_hout_bytes);
     }
     hipStream_t s = m->stream;
     memcpy(m->sm_hin, Xs, sizeof(T) * (size_t)cnt * m->d);
@@ -1615,14 +1712,15 @@ static int model_predict(hbegp_model* m, const T* Xs, int cnt, T* mean, T* var, 
   }
   const int mp = round_up(std::max(cnt, 1), NB);
   if (mp > m->cap_m) {
-    (void)hipFree(m->Xs); (void)hipFree(m->Ks); (void)hipFree(m->Q); (void)hipFree(m->mean); (void)hipFree(m->var);
+    HIPCHECK(hipStreamSynchronize(m->stream));  // nothing of an earlier predict is still using the smaller arrays
+    m->pfree(m->Xs); m->pfree(m->Ks); m->pfree(m->Q); m->pfree(m->mean); m->pfree(m->var);
     m->Xs = m->Ks = m->Q = m->mean = m->var = nullptr;
     m->cap_m = 0;
-    HIPCHECK(hipMalloc(&m->Xs, sizeof(T) * (size_t)mp * m->d));
-    HIPCHECK(hipMalloc(&m->Ks, sizeof(T) * (size_t)mp * m->np));
-    HIPCHECK(hipMalloc(&m->Q, sizeof(T) * (size_t)mp * m->np));
-    HIPCHECK(hipMalloc(&m->mean, sizeof(T) * mp));
-    HIPCHECK(hipMalloc(&m->var, sizeof(T) * mp));
+    m->Xs = m->palloc(sizeof(T) * (size_t)mp * m->d);
+    m->Ks = m->palloc(sizeof(T) * (size_t)mp * m->np);
+    m->Q = m->palloc(sizeof(T) * (size_t)mp * m->np);
+    m->mean = m->palloc(sizeof(T) * mp);
+    m->var = m->palloc(sizeof(T) * mp);
     m->cap_m = mp;
   }
   hipStream_t s = m->stream;
@@ -1728,22 +1826,22 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
       LbfgsState* st = nullptr;
       SmallFitResult* res = nullptr;
       double *x0 = nullptr, *tr_theta = nullptr, *tr_lml = nullptr, *tr_grad = nullptr;
+      std::vector<double> box;  // start point, lower and upper bounds: the source of an asynchronous copy, kept until the run is collected
     };
     const int cap = opt.trace_cap > 0 ? opt.maxeval : 0;  // per run; the merged trace is cut at opt.trace_cap below
     std::vector<RunWs> ws(nruns);
-    auto free_all = [&]() {
-      for (auto& w : ws) {
-        (void)hipSetDevice(ctx->devs[w.di]);
-        (void)hipFree(w.tr_theta); (void)hipFree(w.tr_lml); (void)hipFree(w.tr_grad);
-      }
-    };
+    auto free_all = [&]() {};  // the trace arrays belong to the problem's pooled allocations (released with it)
     try {
       std::vector<int> next_slot(ndev, 0);
+      // the runs of a device are the workgroups of ONE launch on the device's first slot stream (one stream per fit and device:
+      // fits side by side on one GPU then do not queue behind each other's persistent kernels, see small_fit_kernel)
+      std::vector<std::vector<SmallFit>> fits_on(ndev);
       for (int r = 0; r < nruns; ++r) {
         RunWs& w = ws[r];
         w.di = r % ndev; w.si = next_slot[w.di]++; w.run = r;
         HIPCHECK(hipSetDevice(ctx->devs[w.di]));
         Slot<T>& s = prob.slots[w.di][w.si];
+        hipStream_t st = prob.slots[w.di][0].stream;
         // the run's workspace: the slot's W1 (the kernel matrix never leaves the LDS on this path, so the buffer is free) --
         // a hipMalloc / hipFree pair per array cost more than the run's arithmetic
         static_assert(sizeof(LbfgsState) + sizeof(SmallFitResult) + 3 * MAXP * sizeof(double) + 64 <= (size_t)NB * NB * sizeof(float),
@@ -1753,16 +1851,17 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         w.res = reinterpret_cast<SmallFitResult*>(base + (sizeof(LbfgsState) + 15) / 16 * 16);
         w.x0 = reinterpret_cast<double*>(reinterpret_cast<char*>(w.res) + (sizeof(SmallFitResult) + 15) / 16 * 16);
         if (cap > 0) {
-          HIPCHECK(hipMalloc(&w.tr_theta, sizeof(double) * (size_t)cap * p));
-          HIPCHECK(hipMalloc(&w.tr_lml, sizeof(double) * cap));
-          HIPCHECK(hipMalloc(&w.tr_grad, sizeof(double) * (size_t)cap * p));
+          w.tr_theta = prob.template palloc<double>(s.dev, (size_t)cap * p);
+          w.tr_lml = prob.template palloc<double>(s.dev, cap);
+          w.tr_grad = prob.template palloc<double>(s.dev, (size_t)cap * p);
         }
         const double* start = r == 0 ? theta0 : starts + (size_t)(r - 1) * p;
-        std::vector<double> box(3 * (size_t)p);  // start point, lower and upper bounds: one copy
+        std::vector<double>& box = w.box;
+        box.assign(3 * (size_t)p, 0.0);  // start point, lower and upper bounds: one copy
         memcpy(box.data(), start, sizeof(double) * p);
         memcpy(box.data() + p, lo, sizeof(double) * p);
         memcpy(box.data() + 2 * p, hi, sizeof(double) * p);
-        HIPCHECK(hipMemcpy(w.x0, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpyAsync(w.x0, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice, st));
         SmallFit f{};
         f.ev.X = prob.Xd[w.di]; f.ev.y = prob.yd[w.di]; f.ev.n = n; f.ev.d = d; f.ev.P = s.dP;
         f.ev.W2 = s.W2; f.ev.ldiag = s.ldiag; f.ev.out = s.dOut; f.ev.hout = s.dOut;
@@ -1772,7 +1871,15 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         f.maxeval = opt.maxeval; f.memory = opt.lbfgs_memory > 0 ? opt.lbfgs_memory : lo_opt.memory; f.fixed_work = opt.fixed_work != 0;
         f.pgtol = lo_opt.pgtol; f.ftol = lo_opt.ftol;
         f.res = w.res; f.trace_theta = w.tr_theta; f.trace_lml = w.tr_lml; f.trace_grad = w.tr_grad; f.trace_cap = cap;
-        launch_small_fit<T>(f, prob.nu2, s.stream);
+        fits_on[w.di].push_back(f);
+      }
+      for (int di = 0; di < ndev; ++di) {
+        if (fits_on[di].empty()) continue;
+        HIPCHECK(hipSetDevice(ctx->devs[di]));
+        hipStream_t st = prob.slots[di][0].stream;
+        SmallFit* fs_dev = prob.template palloc<SmallFit>(ctx->devs[di], fits_on[di].size());
+        HIPCHECK(hipMemcpyAsync(fs_dev, fits_on[di].data(), sizeof(SmallFit) * fits_on[di].size(), hipMemcpyHostToDevice, st));  // fits_on lives until the runs are collected
+        launch_small_fit<T>(fs_dev, (int)fits_on[di].size(), prob.nu2, st);
         CHECK_LAUNCHES();
       }
       int total_evals = 0, total_not_pd = 0, trace_n = 0;
@@ -1780,9 +1887,11 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         RunWs& w = ws[r];
         HIPCHECK(hipSetDevice(ctx->devs[w.di]));
         Slot<T>& s = prob.slots[w.di][w.si];
-        HIPCHECK(hipStreamSynchronize(s.stream));
+        hipStream_t st = prob.slots[w.di][0].stream;
+        HIPCHECK(hipStreamSynchronize(st));
         SmallFitResult hr;
-        HIPCHECK(hipMemcpy(&hr, w.res, sizeof(hr), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpyAsync(&hr, w.res, sizeof(hr), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
         total_evals += hr.n_evals;
         total_not_pd += hr.n_not_pd;
         s.best_idx = hr.best_idx;
@@ -1790,12 +1899,14 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         s.best_run = r;
         s.best_eval = hr.best_eval;
         s.best_theta.assign(hr.best_theta, hr.best_theta + p);
+        s.best_params.assign(hr.best_params, hr.best_params + p);
         s.last_target = hr.best_idx < 0 ? 0 : hr.best_idx;
         if (cap > 0 && trace_n < opt.trace_cap) {  // the trace, run by run
           const int take = std::min(std::min(hr.n_evals, cap), opt.trace_cap - trace_n);
-          if (opt.trace_theta) HIPCHECK(hipMemcpy(opt.trace_theta + (size_t)trace_n * p, w.tr_theta, sizeof(double) * (size_t)take * p, hipMemcpyDeviceToHost));
-          if (opt.trace_lml) HIPCHECK(hipMemcpy(opt.trace_lml + trace_n, w.tr_lml, sizeof(double) * take, hipMemcpyDeviceToHost));
-          if (opt.trace_grad) HIPCHECK(hipMemcpy(opt.trace_grad + (size_t)trace_n * p, w.tr_grad, sizeof(double) * (size_t)take * p, hipMemcpyDeviceToHost));
+          if (opt.trace_theta) HIPCHECK(hipMemcpyAsync(opt.trace_theta + (size_t)trace_n * p, w.tr_theta, sizeof(double) * (size_t)take * p, hipMemcpyDeviceToHost, st));
+          if (opt.trace_lml) HIPCHECK(hipMemcpyAsync(opt.trace_lml + trace_n, w.tr_lml, sizeof(double) * take, hipMemcpyDeviceToHost, st));
+          if (opt.trace_grad) HIPCHECK(hipMemcpyAsync(opt.trace_grad + (size_t)trace_n * p, w.tr_grad, sizeof(double) * (size_t)take * p, hipMemcpyDeviceToHost, st));
+          HIPCHECK(hipStreamSynchronize(st));
           if (opt.trace_run) for (int e = 0; e < take; ++e) opt.trace_run[trace_n + e] = r;
           trace_n += take;
         }
@@ -1805,11 +1916,10 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
       if (opt.n_not_pd) *opt.n_not_pd = total_not_pd;
       n_evals.store(total_evals);
     } catch (...) {
-      for (auto& w : ws) {  // let the launched kernels finish before their workspaces go
-        if (w.di < (int)prob.slots.size() && w.si < (int)prob.slots[w.di].size()) {
-          (void)hipSetDevice(ctx->devs[w.di]);
-          (void)hipStreamSynchronize(prob.slots[w.di][w.si].stream);
-        }
+      for (int di = 0; di < ndev && di < (int)prob.slots.size(); ++di) {  // let the launched kernels finish before their workspaces go
+        if (prob.slots[di].empty()) continue;
+        (void)hipSetDevice(ctx->devs[di]);
+        (void)hipStreamSynchronize(prob.slots[di][0].stream);
       }
       free_all();
       throw;
@@ -1822,8 +1932,13 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   auto worker = [&](int di, int si) {
     struct Leave {
       std::atomic<int>* busy;
-      ~Leave() { if (busy) busy->fetch_sub(1); }
-    } leave{prob.busy_slots_ ? &prob.busy_slots_[di] : nullptr};
+      std::atomic<int>* dev_busy;
+      ~Leave() {
+        if (busy) busy->fetch_sub(1);
+        if (dev_busy) dev_busy->fetch_sub(1);
+      }
+    } leave{prob.busy_slots_ ? &prob.busy_slots_[di] : nullptr, ctx->devs[di] < MAX_DEVS ? &g_dev_busy[ctx->devs[di]] : nullptr};
+    if (leave.dev_busy) leave.dev_busy->fetch_add(1);
     try {
       HIPCHECK(hipSetDevice(ctx->devs[di]));
       Slot<T>& s = prob.slots[di][si];
@@ -1942,7 +2057,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   if (theta_best) memcpy(theta_best, th.data(), sizeof(double) * p);
   if (lml_best) *lml_best = best.best_lml;
   const auto tf2 = std::chrono::steady_clock::now();
-  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml);
+  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data());
   if (timing) {
     const auto tf3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2147,11 +2262,14 @@ static int problem_get(hbegp_problem* prob, int dev, int slot, T* alpha, T* kinv
   Slot<T>& s = p->slots[dev][slot];
   HIPCHECK(hipSetDevice(s.dev));
   const int b = s.last_target, n = p->n, np = p->np;
-  if (alpha) HIPCHECK(hipMemcpy(alpha, s.alpha[b], sizeof(T) * n, hipMemcpyDeviceToHost));
-  if (ldiag) HIPCHECK(hipMemcpy(ldiag, s.ldiag, sizeof(T) * n, hipMemcpyDeviceToHost));
+  // (copies on the slot's own stream: a null-stream copy fails while another host thread captures a graph)
+  if (alpha) HIPCHECK(hipMemcpyAsync(alpha, s.alpha[b], sizeof(T) * n, hipMemcpyDeviceToHost, s.stream));
+  if (ldiag) HIPCHECK(hipMemcpyAsync(ldiag, s.ldiag, sizeof(T) * n, hipMemcpyDeviceToHost, s.stream));
+  HIPCHECK(hipStreamSynchronize(s.stream));
   if (kinv) {
     std::vector<T> tmp((size_t)np * np);
-    HIPCHECK(hipMemcpy(tmp.data(), s.Kinv[b], sizeof(T) * tmp.size(), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpyAsync(tmp.data(), s.Kinv[b], sizeof(T) * tmp.size(), hipMemcpyDeviceToHost, s.stream));
+    HIPCHECK(hipStreamSynchronize(s.stream));
     for (int i = 0; i < n; ++i)
       for (int j = 0; j <= i; ++j) kinv[(size_t)i * n + j] = kinv[(size_t)j * n + i] = tmp[(size_t)i * np + j];
   }
@@ -2171,7 +2289,8 @@ static int problem_debug_get(hbegp_problem* prob, int dev, int slot, int which, 
   HIPCHECK(hipStreamSynchronize(s.stream));
   const T* src = which == 1 ? s.W1 : (which == 2 ? s.W2 : (which == 3 ? s.W3 : s.Kinv[s.last_target]));
   if (!src) return fail(HBEGP_EINVAL, "this problem has no such work matrix");
-  HIPCHECK(hipMemcpy(out, src, sizeof(T) * (size_t)p->np * p->np, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpyAsync(out, src, sizeof(T) * (size_t)p->np * p->np, hipMemcpyDeviceToHost, s.stream));
+  HIPCHECK(hipStreamSynchronize(s.stream));
   return HBEGP_OK;
   GUARD_END
 }
@@ -2202,7 +2321,7 @@ static int problem_kmat(hbegp_problem* prob, int dev, int slot, const double* th
   theta_to_params(theta, lo, hi, p->d, s.hP);
   HIPCHECK(hipMemcpyAsync(s.dP, s.hP, sizeof(EvalParams), hipMemcpyHostToDevice, s.stream));
   launch_reset_out(s.dOut, s.stream);
-  launch_kmat<T>(p->Xd[dev], p->n, p->d, p->np, p->nu2, s.dP, s.W1, &s.dOut->info, s.stream, s.tickets + 2);
+  launch_kmat<T>(p->Xd[dev], p->n, p->d, p->np, p->nu2, s.dP, s.W1, &s.dOut->info, s.stream);
   CHECK_LAUNCHES();
   const int n = p->n, np = p->np;
   std::vector<T> tmp((size_t)np * np);
@@ -2322,8 +2441,9 @@ static int model_get(hbegp_model* m, double* theta, T* alpha, T* kinv) {
   std::lock_guard<std::mutex> lock(m->mu);
   HIPCHECK(hipSetDevice(m->dev));
   if (theta) memcpy(theta, m->theta.data(), sizeof(double) * m->theta.size());
-  if (alpha) HIPCHECK(hipMemcpy(alpha, m->alpha, sizeof(T) * m->n, hipMemcpyDeviceToHost));
-  if (kinv) HIPCHECK(hipMemcpy2D(kinv, sizeof(T) * m->n, m->Kinv, sizeof(T) * m->np, sizeof(T) * m->n, m->n, hipMemcpyDeviceToHost));
+  if (alpha) HIPCHECK(hipMemcpyAsync(alpha, m->alpha, sizeof(T) * m->n, hipMemcpyDeviceToHost, m->stream));
+  if (kinv) HIPCHECK(hipMemcpy2DAsync(kinv, sizeof(T) * m->n, m->Kinv, sizeof(T) * m->np, sizeof(T) * m->n, m->n, hipMemcpyDeviceToHost, m->stream));
+  HIPCHECK(hipStreamSynchronize(m->stream));
   return HBEGP_OK;
   GUARD_END
 }
@@ -2339,6 +2459,29 @@ void hbegp_model_retain(hbegp_model* model) {
 }
 void hbegp_model_release(hbegp_model* model) {
   if (model && model->refs.fetch_sub(1) == 1) delete model;
+}
+
+int hbegp_debug_lbfgs_replay(int n, const double* x0, const double* lo, const double* hi, int maxeval, int memory, int fixed_work,
+                             int count, const double* f, const double* g, double* requested, int* n_requested) {
+  if (n < 1 || n > LBFGS_MAXN || count < 0 || !x0 || !lo || !hi || !requested || !n_requested || (count > 0 && (!f || !g)))
+    return fail(HBEGP_EINVAL, "bad argument");
+  GUARD_BEGIN
+  LbfgsOptions o;
+  std::unique_ptr<LbfgsState> st(new LbfgsState);
+  lbfgs_begin(*st, x0, lo, hi, n, maxeval, memory > 0 ? memory : o.memory, o.pgtol, o.ftol, fixed_work != 0);
+  int produced = 0;
+  memcpy(requested, lbfgs_request(*st), sizeof(double) * n);
+  produced = 1;
+  for (int i = 0; i < count; ++i) {
+    if (!lbfgs_advance(*st, f[i], g + (size_t)i * n)) break;
+    if (i + 1 < count) {
+      memcpy(requested + (size_t)(i + 1) * n, lbfgs_request(*st), sizeof(double) * n);
+      produced = i + 2;
+    }
+  }
+  *n_requested = produced;
+  return HBEGP_OK;
+  GUARD_END
 }
 
 int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, int* ntasks, int* ncounters, int* nleaf,

@@ -1090,10 +1090,13 @@ __device__ __forceinline__ void eval_prologue(const EvalParams* __restrict__ P, 
 
 // ---- what kmat_kernel and gradtrace_kernel share (round 5) --------------------------------------------------------------
 // Tiles of 64x64 entries; thread (tx = t&15, ty = t>>4) owns rows ty+16*r, cols 4*tx..4*tx+3.
-//  * The tiles of a launch are dealt through a QUEUE (one returning atomic per tile): the launches used to have one workgroup
-//    per tile -- 2,080 of them at n = 4096, 2,048 resident at once and 32 left over that ran a second, nearly empty round; and
-//    inside a fit only the CUs no task-queue workgroup sits on are free, a number that changes while the launch runs.
-//    The workgroup that draws the very last ticket (ntiles + gridDim.x - 1) leaves the counter at zero for the next launch.
+//  * One workgroup per tile, dealt by the hardware dispatcher (which refills a CU the moment a workgroup leaves it).  Round 5
+//    tried persistent workgroups fed through a software queue (one returning atomic on one queue word per tile):
+//    2,080 grabs on one word cost more than the tiles (kmat 30 -> 45 us, gradtrace 48 -> 86 us alone, worse with more workgroups
+//    per CU; profiles/r05_tail_kernels_queue.txt) -- removed.  Capping the occupancy through a larger LDS request (3 / 4 / 5 / 8
+//    workgroups per CU, so that the dispatcher has tiles left to balance the end of the launch with) changed nothing either
+//    (kmat 35.0 / 30.5 / 30.5 / 30.6 us, gradtrace 50.6 / 43.7 / 44.3 / 43.8 us): both kernels sit at ~64 % of the fp64 VALU issue
+//    rate (kmat: ~75 fp64 instructions per entry, 8.4 M entries = 19 us at 100 %), bound by their sqrt / exp sequences.
 //  * The j tile's features sit in the LDS so that a thread's four columns are ONE conflict-free 16-byte read (f32) or two
 //    (f64: [k][half][tx][2] -- a 16-lane group then reads 256 contiguous bytes); the plain [k][64] layout made the f64 reads
 //    2-way conflicted (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 45 % in kmat, 20 % in gradtrace, profiles/r04_pmc_sq.json).
@@ -1112,29 +1115,17 @@ __device__ __forceinline__ void read_xj4(const T* xj, int k, int tx, T (&b)[4]) 
     b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
   }
 }
-// next tile of the launch (uniform), or -1; ends with a barrier, so the previous tile's LDS operands are free to be overwritten
-__device__ __forceinline__ int next_tile(int* queue, int ntiles, int* s_tile) {
-  if (threadIdx.x == 0) {
-    int tk = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == ntiles + (int)gridDim.x - 1) __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the last ticket of the launch
-    *s_tile = tk < ntiles ? tk : -1;
-  }
-  __syncthreads();
-  return *s_tile;
-}
-
 // NU2: the Matern order at compile time (no branch per entry); tiles that lie wholly inside the n x n matrix skip the
 // per-entry bounds tests.
 template <typename T, int NU2>
 __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int n, int d, int np,
                                                    const EvalParams* __restrict__ P, T* __restrict__ W,
-                                                   const int* info, EvalPrologue pro, int* queue, int ntiles) {
+                                                   const int* info, EvalPrologue pro) {
   if (pro.dP) {
     // first kernel of an evaluation (engine.hpp, EvalPrologue): nothing has failed yet, `info` still holds the previous
     // evaluation's value and is not read; workgroup 0 prepares the device-side blocks for the kernels behind this one
     if (blockIdx.x == 0) eval_prologue(P, pro);
   } else if (*info != 0) {
-    // the queue is not touched: it stays at zero for the next launch
     return;
   }
   extern __shared__ __align__(16) char smem_raw[];
@@ -1144,14 +1135,13 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
   // the parameters once per workgroup: in an evaluation driven through pinned memory P is a host block, and every read of it is
   // an uncached round trip over the host link (per-thread reads made the launch 10 us longer at n=4096)
   __shared__ double sp[MAXP];
-  __shared__ int s_tile;
   if (t < d + 2) sp[t] = reinterpret_cast<const double*>(P)[t];
   static_assert(offsetof(EvalParams, noise) == 0 && offsetof(EvalParams, amp) == 8 && offsetof(EvalParams, ell) == 16, "EvalParams: noise, amp, ell[]");
   const int tx = t & 15, ty = t >> 4;
   typedef T vec4 __attribute__((ext_vector_type(4)));
-  for (;;) {
-    const int tile = next_tile(queue, ntiles, &s_tile);  // (its barrier also orders the reads of sp behind their writes)
-    if (tile < 0) break;
+  __syncthreads();
+  {
+    const int tile = blockIdx.x;
     const int li = tri_row(tile), lj = tile - li * (li + 1) / 2;
     const int i0 = li * 64, j0 = lj * 64;
     for (int e = t; e < 64 * d; e += 256) {
@@ -1191,7 +1181,7 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
         for (int c = 0; c < 4; ++c) out[c] = kmat_entry<T>(acc[r][c], NU2, amp, noise, dtile && gi == j0 + tx * 4 + c);
         *reinterpret_cast<vec4*>(W + (size_t)gi * np + j0 + tx * 4) = out;
       }
-      continue;
+      return;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1208,28 +1198,22 @@ __global__ void __launch_bounds__(256) kmat_kernel(const T* __restrict__ X, int 
   }
 }
 
-// workgroups of a queue-fed launch: enough to fill the chip at the kernel's occupancy, never more than tiles
-static int queue_grid(int ntiles) {
-  static const int per_cu = [] { const char* v = getenv("HBEGP_TILE_WGS_PER_CU"); return v ? std::max(1, atoi(v)) : 6; }();
-  return std::max(1, std::min(ntiles, 256 * per_cu));
-}
-
 template <typename T>
 void launch_kmat(const T* X, int n, int d, int np, int nu2, const EvalParams* P, T* W, const int* info, hipStream_t s,
-                 int* queue, const EvalPrologue* pro) {
+                 const EvalPrologue* pro) {
   const int nt = np / 64, ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
-  const dim3 grid(queue_grid(ntiles)), block(256);
+  const dim3 grid(ntiles), block(256);
   const EvalPrologue pr = pro ? *pro : EvalPrologue{};
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
-    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
-    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
-    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info, pr, queue, ntiles); break;
+    case 0: hipLaunchKernelGGL((kmat_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    case 1: hipLaunchKernelGGL((kmat_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    case 3: hipLaunchKernelGGL((kmat_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
+    default: hipLaunchKernelGGL((kmat_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, W, info, pr); break;
   }
 }
-template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t, int*, const EvalPrologue*);
-template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t, int*, const EvalPrologue*);
+template void launch_kmat<double>(const double*, int, int, int, int, const EvalParams*, double*, const int*, hipStream_t, const EvalPrologue*);
+template void launch_kmat<float>(const float*, int, int, int, int, const EvalParams*, float*, const int*, hipStream_t, const EvalPrologue*);
 
 // =================================================================================================================
 // alpha = K^-1 y through the explicit inverse factor: w = X y, alpha = X^T w;  lml pieces (lml.rs:54-59)
@@ -1268,21 +1252,6 @@ __device__ __forceinline__ bool last_workgroup(int* ticket) {
   }
   __syncthreads();
   const bool last = s_last != 0;
-  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return last;
-}
-// The same for a queue-fed launch: the ticket counts finished TILES (this workgroup hands in `mine` of `total`), so a workgroup
-// that found the queue empty takes no part.  Call with mine > 0, by the whole workgroup, every publishing wave drained.
-__device__ __forceinline__ bool last_of_tiles(int* ticket, int mine, int total) {
-  __shared__ int s_last_t;
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int tk = __hip_atomic_fetch_add(ticket, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last_t = tk + mine == total;
-    if (s_last_t) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const bool last = s_last_t != 0;
   if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return last;
 }
@@ -1670,42 +1639,29 @@ template <typename T, int NU2>
 __global__ void __launch_bounds__(256) gradtrace_kernel(const T* __restrict__ X, int n, int d, int np,
                                                         const EvalParams* __restrict__ P, const T* __restrict__ Kinv,
                                                         const T* __restrict__ alpha, double* __restrict__ part,
-                                                        const int* info, GradFinish fin, int* queue, int ntiles) {
+                                                        const int* info, GradFinish fin) {
   extern __shared__ __align__(16) char smem_raw[];
   T* xi = reinterpret_cast<T*>(smem_raw);  // [d][64] raw features of the i tile
   T* xj = xi + (size_t)d * 64;             // j tile, xj_index layout
   __shared__ double red[(GT_CHUNK + 2) * 256];
   __shared__ double inv_l2[MAXD];
-  __shared__ int s_tile;
   const bool failed = *info != 0;
   const int t = threadIdx.x;
-  int mine = 0;  // tiles this workgroup has done (uniform)
   if (!failed) {
     if (t < d) {
       const T ell = (T)P->ell[t];
       inv_l2[t] = (double)(T(1) / (ell * ell));  // 1/scales_k_square (matern_kernel.rs:94-98)
     }
     const T amp = (T)P->amp, noise = (T)P->noise;
-    for (;;) {
-      const int tile = next_tile(queue, ntiles, &s_tile);
-      if (tile < 0) break;
-      gradtrace_tile<T, NU2>(tile, X, n, d, np, amp, noise, inv_l2, Kinv, alpha, part, xi, xj, red);
-      ++mine;
-    }
+    gradtrace_tile<T, NU2>((int)blockIdx.x, X, n, d, np, amp, noise, inv_l2, Kinv, alpha, part, xi, xj, red);
   }
   if (!fin.out) return;
-  if (failed) {
-    // no tile ran: every workgroup hands in one ticket, the last one publishes the (failed) evaluation
-    if (!last_workgroup(fin.ticket)) return;
-  } else {
-    if (mine == 0) return;
-    // every publishing lane (lane 0 of each wave) has its stores in the L2 before thread 0 hands in the workgroup's tiles
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!last_of_tiles(fin.ticket, mine, ntiles)) return;
-  }
+  // every publishing lane (lane 0 of each wave) has its stores in the L2 before thread 0 takes the launch's ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!last_workgroup(fin.ticket)) return;
   if (!failed) {
-    finalize_grad_in_block(part, ntiles, d + 2, fin.out);
+    finalize_grad_in_block(part, (int)gridDim.x, d + 2, fin.out);
     if (threadIdx.x == 0) atomicOr(&fin.out->done, 2);
   }
   __syncthreads();
@@ -1734,25 +1690,25 @@ size_t gradtrace_part_elems(int np, int d) {
 
 template <typename T>
 void launch_gradtrace(const T* X, int n, int d, int np, int nu2, const EvalParams* P, const T* Kinv, const T* alpha,
-                      double* part, EvalOut* out, const int* info, hipStream_t s, int* queue, int* ticket, EvalOut* hout) {
+                      double* part, EvalOut* out, const int* info, hipStream_t s, int* ticket, EvalOut* hout) {
   const int nt = np / 64;
   const int ntiles = nt * (nt + 1) / 2;
   const size_t lds = (size_t)2 * d * 64 * sizeof(T);
-  const dim3 grid(queue_grid(ntiles)), block(256);
+  const dim3 grid(ntiles), block(256);
   GradFinish fin;
   if (ticket) { fin.out = out; fin.hout = hout; fin.ticket = ticket; }
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
-    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
-    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
-    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin, queue, ntiles); break;
+    case 0: hipLaunchKernelGGL((gradtrace_kernel<T, 0>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    case 1: hipLaunchKernelGGL((gradtrace_kernel<T, 1>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    case 3: hipLaunchKernelGGL((gradtrace_kernel<T, 3>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
+    default: hipLaunchKernelGGL((gradtrace_kernel<T, 5>), grid, block, lds, s, X, n, d, np, P, Kinv, alpha, part, info, fin); break;
   }
   if (!ticket) hipLaunchKernelGGL(finalize_grad_kernel, dim3(d + 2), dim3(256), 0, s, part, ntiles, d + 2, out, info);
 }
 template void launch_gradtrace<double>(const double*, int, int, int, int, const EvalParams*, const double*, const double*,
-                                       double*, EvalOut*, const int*, hipStream_t, int*, int*, EvalOut*);
+                                       double*, EvalOut*, const int*, hipStream_t, int*, EvalOut*);
 template void launch_gradtrace<float>(const float*, int, int, int, int, const EvalParams*, const float*, const float*,
-                                      double*, EvalOut*, const int*, hipStream_t, int*, int*, EvalOut*);
+                                      double*, EvalOut*, const int*, hipStream_t, int*, EvalOut*);
 
 // =================================================================================================================
 // symmetrize: mirror the lower triangle into the upper one (what invc() hands back, lml.rs:62)
@@ -2627,7 +2583,11 @@ __device__ __attribute__((noinline)) void small_eval_call(const SmallEval* g, ch
 // side by side, and collects.  The ~40 us round trip through the host per evaluation (graph launch + completion wake-up +
 // three host threads on the runtime's lock) becomes ~5 us of wave-wide vector arithmetic.
 template <typename TIO, int NU2>
-__global__ void __launch_bounds__(512, 2) small_fit_kernel(SmallFit f) {
+__global__ void __launch_bounds__(512, 2) small_fit_kernel(const SmallFit* __restrict__ fs) {
+  // one workgroup = one optimiser run: the runs of a fit are the workgroups of ONE launch (round 4: one launch per run on a
+  // stream of its own -- three streams per fit, and HIP maps streams onto a handful of hardware queues: fits side by side
+  // then queued behind each other's persistent kernels)
+  const SmallFit f = fs[blockIdx.x];
   extern __shared__ __align__(16) char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -2642,12 +2602,14 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(SmallFit f) {
   WaveLbfgs w{};
   int best_idx = -1, best_eval = 0, n_evals = 0, n_not_pd = 0;
   double best_lml = -INFINITY;
+  double cur_param = 0.0;  // wave 0, lane = parameter: what the evaluation in flight runs with
   // wave 0: the requested point -> clamped linear-space parameters (fit.rs:94-96; the noise is not clamped, :96)
   auto publish_request = [&]() {
     if (act) {
       const double th = w.phase == 1 ? st->xn[lane] : st->x[lane];
       double v = exp(th);
       if (lane >= 1) v = v < f.lo[lane] ? f.lo[lane] : (f.hi[lane] < v ? f.hi[lane] : v);  // bounded_value.rs:43-56
+      cur_param = v;
       if (lane == 0) P->noise = v;
       else if (lane == 1) P->amp = v;
       else P->ell[lane - 2] = v;
@@ -2704,7 +2666,10 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(SmallFit f) {
         best_idx = target;
         best_lml = lml;
         best_eval = eval_idx;
-        if (act) res->best_theta[lane] = th;
+        if (act) {
+          res->best_theta[lane] = th;
+          res->best_params[lane] = cur_param;
+        }
       }
       // fit.rs:128-133: the optimiser minimises -lml
       const bool more = wl_advance(w, st, lane, act, ok ? -lml : INFINITY, -ge, f.maxeval, f.memory < 1 ? 1 : (f.memory > LBFGS_MAXM ? LBFGS_MAXM : f.memory),
@@ -2727,18 +2692,18 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(SmallFit f) {
 }
 
 template <typename T>
-void launch_small_fit(const SmallFit& f, int nu2, hipStream_t s) {
-  const dim3 grid(1), block(512);
+void launch_small_fit(const SmallFit* fs_dev, int nruns, int nu2, hipStream_t s) {
+  const dim3 grid(nruns), block(512);
   const size_t lds = 163840;  // the whole LDS of a CU
   switch (nu2) {
-    case 0: hipLaunchKernelGGL((small_fit_kernel<T, 0>), grid, block, lds, s, f); break;
-    case 1: hipLaunchKernelGGL((small_fit_kernel<T, 1>), grid, block, lds, s, f); break;
-    case 3: hipLaunchKernelGGL((small_fit_kernel<T, 3>), grid, block, lds, s, f); break;
-    default: hipLaunchKernelGGL((small_fit_kernel<T, 5>), grid, block, lds, s, f); break;
+    case 0: hipLaunchKernelGGL((small_fit_kernel<T, 0>), grid, block, lds, s, fs_dev); break;
+    case 1: hipLaunchKernelGGL((small_fit_kernel<T, 1>), grid, block, lds, s, fs_dev); break;
+    case 3: hipLaunchKernelGGL((small_fit_kernel<T, 3>), grid, block, lds, s, fs_dev); break;
+    default: hipLaunchKernelGGL((small_fit_kernel<T, 5>), grid, block, lds, s, fs_dev); break;
   }
 }
-template void launch_small_fit<double>(const SmallFit&, int, hipStream_t);
-template void launch_small_fit<float>(const SmallFit&, int, hipStream_t);
+template void launch_small_fit<double>(const SmallFit*, int, int, hipStream_t);
+template void launch_small_fit<float>(const SmallFit*, int, int, hipStream_t);
 
 template <typename T>
 void launch_small_eval(const SmallEval& g, int nu2, hipStream_t s) {

@@ -4,9 +4,13 @@
 // problems of at most 128 rows one evaluation is a single workgroup's work (small_eval_kernel), and the round trip through
 // the host (graph launch + completion wake-up + three host threads on the runtime's lock: ~40 us) is as long as the
 // evaluation.  Here the same algorithm is turned inside out: lbfgs_begin() returns the first point to evaluate,
-// lbfgs_advance() takes that evaluation's (f, grad) and returns the next point or "finished" -- a persistent kernel
-// (small_fit_kernel) runs a whole optimiser run on the device with it, and the host path runs on it too, so there is ONE
-// implementation of the method (tests/cpp/test_lbfgs_step.cpp replays lbfgsb_minimize's iterate sequence bit for bit on the host).
+// lbfgs_advance() takes that evaluation's (f, grad) and returns the next point or "finished".  The HOST path runs on it
+// (lbfgsb_minimize is a loop around it; tests/cpp/test_lbfgs_step.cpp replays the old loop form's iterate sequence bit for bit).
+// The persistent kernel (small_fit_kernel) shares the state layout (LbfgsState) and the method, but NOT this code: one thread
+// walking it took 70 us per evaluation, so wave 0 runs a wave-wide transcription (kernels.hip: wl_begin_iteration / wl_advance --
+// lane = dimension, dot products as DPP reductions, i.e. sums in another order, and the device's exp for theta -> parameters).
+// That transcription is pinned against this file on the GPU: tests/test_gpu_fit.py replays a device run's trace
+// (theta_i, f_i, g_i) through lbfgs_advance on the host and checks every next point it asks for.
 //
 // Same method, same constants, same evaluation counting as lbfgsb.hpp: projected L-BFGS (src/util/gradmin.rs:35-60 calls
 // NLopt's bounded L-BFGS with maxeval = 150) -- active set from the sign of the gradient at the bounds, two-loop recursion

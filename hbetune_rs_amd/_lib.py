@@ -85,6 +85,7 @@ SIGNATURES = {
     "hbegp_model_get_f32": (C.c_int, [_vp, _dp, _fp, _fp]),
     "hbegp_model_retain": (None, [_vp]),
     "hbegp_model_release": (None, [_vp]),
+    "hbegp_debug_lbfgs_replay": (C.c_int, [C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _ip]),
     "hbegp_debug_dag_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _dp, _dp, _dp, C.c_char_p,
                                        C.c_int]),
     "hbegp_minimize_by_gradient": (C.c_double, [OBJECTIVE_FN, _vp, _dp, _dp, _dp, C.c_int, C.c_int]),

@@ -302,6 +302,31 @@ def test_extend_repeats_the_fits_own_evaluation_bit_for_bit(n, dtype, n_restarts
     ex.release()
 
 
+def _replay_on_host_state_machine(tr, w, starts, maxeval, fixed_work):
+    import ctypes as C
+
+    from hbetune_rs_amd import _lib
+
+    lib = _lib.load()
+    p = len(w["theta0"])
+    lnlo, lnhi = np.log(w["lo"]), np.log(w["hi"])
+    worst = 0.0
+    for r in sorted(set(tr["run"].tolist())):
+        idx = np.nonzero(tr["run"] == r)[0]
+        th = np.ascontiguousarray(tr["theta"][idx])
+        f = np.ascontiguousarray(np.where(np.isfinite(tr["lml"][idx]), -tr["lml"][idx], np.inf))
+        g = np.ascontiguousarray(-tr["grad"][idx])
+        x0 = np.ascontiguousarray(w["theta0"] if r == 0 else starts[r - 1], dtype=np.float64)
+        req = np.zeros((len(idx), p))
+        nreq = C.c_int(0)
+        rc = lib.hbegp_debug_lbfgs_replay(p, _lib.dptr(x0), _lib.dptr(np.ascontiguousarray(lnlo)), _lib.dptr(np.ascontiguousarray(lnhi)), maxeval, 0,
+                                          1 if fixed_work else 0, len(idx), _lib.dptr(f), _lib.dptr(g), _lib.dptr(req), C.byref(nreq))
+        assert rc == 0
+        assert nreq.value == len(idx), (r, nreq.value, len(idx))  # the host would have stopped where the device stopped
+        worst = max(worst, float(np.max(np.abs(req - th) / np.maximum(1.0, np.abs(th)))))
+    return worst
+
+
 @pytest.mark.parametrize("n,cfg,dtype,fixed_work", [(100, "C2", np.float64, False), (128, "M", np.float64, True), (64, "C1", np.float64, False),
                                                      (90, "C5", np.float32, False)])
 def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_work, monkeypatch):
@@ -381,6 +406,14 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
         rf.close()
     mean, var, _ = fk.predict(X[:5])
     assert np.all(np.isfinite(mean)) and np.all(var >= 0)
+    # (c) the device's optimiser against the host state machine (csrc/lbfgs_step.hpp): every run's recorded evaluations
+    # (theta_i, f_i, g_i) are fed to lbfgs_advance on the host, which must ask for the very points the device went on to
+    # evaluate -- start point, line-search trials, bound hits, failed evaluations (+inf), and in fixed-work mode the repeats at
+    # the incumbent.  Same method, sums in another order: 1e-9 of max(1, |theta|) per step (the host's state follows its own
+    # iterates, so a difference would compound).
+    worst_step = _replay_on_host_state_machine(tr, w, starts, maxeval, fixed_work)
+    print(f"device optimiser vs host state machine: worst |theta_dev - theta_host| / max(1, |theta|) over {len(tr['lml'])} evaluations {worst_step:.2e}")
+    assert worst_step <= 1e-9
     lml_dev, n_dev = fk.lml, fk.n_evals
     fk.release()
     # the same fit with the host in the loop
@@ -392,3 +425,48 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
     assert abs(fh.lml - fd.lml) <= (1e-6 if dtype == np.float64 else 1e-3) * max(1.0, abs(fh.lml)), (fh.lml, fd.lml, fh.n_evals, fd.n_evals)
     fh.release()
     fd.release()
+
+
+@pytest.mark.parametrize("n,dtype", [(100, np.float64), (400, np.float64), (900, np.float64), (900, np.float32)])
+def test_concurrent_fits_on_one_context_reproduce_the_solo_fit(n, dtype):
+    # Replicas: several host threads fit side by side on ONE context / ONE GPU -- the library is re-entrant per
+    # context (include/hbegp.h).  Every fit owns its problem (slots, streams, graphs); what they share is process-wide: the
+    # block / stream pools, the plan cache, the device.  Nothing on the fit path touches the null stream or synchronises the
+    # whole device (either would fail or serialise under another thread's graph capture), and the task-queue launches are sized
+    # for the runs in flight over ALL fits.  Same arithmetic whatever the launch size: every concurrent fit must return the solo
+    # fit's model bit for bit -- persistent fit kernel (n = 100), launch path (400), task queue (900), both element types.
+    import threading
+
+    w = synth.make_workload("M", n=n)
+    X, y = w["X"].astype(dtype), w["y"].astype(dtype)
+    starts = synth.restart_points("M", w["lo"], w["hi"], 2)
+    ctx = gpr.Context(device_ids=[0])
+
+    def fit():
+        fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, ctx=ctx, maxeval=25, fixed_work=True)
+        alpha, kinv = fk.arrays()
+        mean, var, _ = fk.predict(X[:7])
+        out = (fk.lml, fk.theta.copy(), alpha, kinv, mean, var)
+        fk.release()
+        return out
+
+    solo = fit()
+    results, errors = [], []
+
+    def work():
+        try:
+            for _ in range(2):
+                results.append(fit())
+        except Exception as e:  # noqa: BLE001 -- the assertion below reports it
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    ctx.close()
+    assert not errors, errors
+    assert len(results) == 8
+    for r in results:
+        assert r[0] == solo[0] and np.array_equal(r[1], solo[1])
+        for a, b in zip(r[2:], solo[2:]):
+            assert np.array_equal(a, b)

@@ -430,8 +430,13 @@ def test_fresh_pool_blocks_are_cleared_before_their_first_writer(dtype, monkeypa
     monkeypatch.setenv("HBEGP_POOL_NULL_DELAY_MB", "8192")
 
     def run():
+        import time
+
         fk = gpr.FittedKernel.extend(X, y, theta)
         try:
+            # an unsynchronised clear is queued behind ~3 ms of null-stream fill per work matrix (six of them): by now it has
+            # landed on top of the model's arrays, which were filled the moment they were handed out
+            time.sleep(0.3)
             mean, var, _ = fk.predict(Xs)
             alpha, _ = fk.arrays()
         finally:

@@ -1,6 +1,7 @@
-"""CPU: the resumable L-BFGS (csrc/lbfgs_step.hpp -- the form the persistent fit kernel runs on the device, and the host path
-too) evaluates exactly the points of the loop form it was derived from (lbfgsb_minimize_loops), bit for bit: 14 objectives incl.
-bounds, failing evaluations, fixed work, tiny budgets, 66 dimensions (tests/cpp/test_lbfgs_step.cpp)."""
+"""CPU: the resumable L-BFGS (csrc/lbfgs_step.hpp -- what the host path runs; the persistent fit kernel runs a wave-wide
+transcription of it, pinned on the GPU by tests/test_gpu_fit.py::test_device_optimiser_follows_the_host_state_machine) evaluates
+exactly the points of the loop form it was derived from (lbfgsb_minimize_loops), bit for bit: 14 objectives incl. bounds, failing
+evaluations, fixed work, tiny budgets, 66 dimensions (tests/cpp/test_lbfgs_step.cpp)."""
 import os
 import subprocess
 

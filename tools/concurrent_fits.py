@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""k independent fixed-work fits side by side on ONE GPU, one host thread each, one context (replicas).
+Usage: concurrent_fits.py n k [k ...]   -> aggregate fits/s per k, and whether every concurrent fit reproduced the solo fit's bits;
+the last line is the same as JSON.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a
+queue run one after the other: set GPU_MAX_HW_QUEUES >= 3 x fits (one stream per optimiser run; up to 128 rows one per fit)."""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hbetune_rs_amd import gpr, synth  # noqa: E402
+
+n = int(sys.argv[1])
+ks = [int(a) for a in sys.argv[2:]] or [1, 2, 4]
+dtype = np.float32 if os.environ.get("FIT_F32") else np.float64
+w = synth.make_workload("M", n=n)
+X, y = w["X"].astype(dtype), w["y"].astype(dtype)
+starts = synth.restart_points("M", w["lo"], w["hi"], 2)
+ctx = gpr.Context(device_ids=[0])
+
+
+def fit():
+    fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, nu=2.5, ctx=ctx, maxeval=150, fixed_work=True)
+    mean, var, _ = fk.predict(X[:8])  # (the whole K^-1 is a 134 MB copy at n = 4096: the predictions stand in for the model's bits)
+    out = (fk.lml, fk.theta.copy(), np.concatenate([mean, var]))
+    fk.release()
+    return out
+
+
+solo = fit()
+summary = {"n": n, "dtype": np.dtype(dtype).name, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"), "fits_per_s": {}, "bitwise_equal_to_solo": True}
+for k in ks:
+    reps = max(2, 24 // k) if n <= 256 else max(2, 8 // k)
+    results = [[] for _ in range(k)]
+
+    def work(i):
+        for _ in range(reps):
+            results[i].append(fit())
+
+    for _ in range(1):  # warm-up round: every thread's pools
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    results = [[] for _ in range(k)]
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    dt = time.perf_counter() - t0
+    same = all(r[0] == solo[0] and np.array_equal(r[1], solo[1]) and np.array_equal(r[2], solo[2]) for rs in results for r in rs)
+    print(f"n={n} {np.dtype(dtype).name} k={k}: {k * reps / dt:.2f} fits/s aggregate ({dt / reps * 1e3:.1f} ms per round of {k}); "
+          f"every fit bit for bit the solo fit: {same}", flush=True)
+    summary["fits_per_s"][str(k)] = k * reps / dt
+    summary["bitwise_equal_to_solo"] = bool(summary["bitwise_equal_to_solo"] and same)
+ctx.close()
+print(json.dumps(summary), flush=True)
