@@ -100,8 +100,8 @@ class DagBuilder {
   }
   // right-looking plan, round 4: the inverse of the factor and K^-1 follow the diagonal chain row by row (rl_progressive)
   // instead of by divide and conquer behind it
-  void set_rl_progressive(bool on, int unear = -1, int knear = -1, bool small_tiles = false, int ratio = 0) {
-    rl_prog_ = on; prog_unear_ = unear; prog_knear_ = knear; prog_small_ = small_tiles; prog_ratio_ = ratio;
+  void set_rl_progressive(bool on, int unear = -1, int knear = -1, bool small_tiles = false) {
+    rl_prog_ = on; prog_unear_ = unear; prog_knear_ = knear; prog_small_ = small_tiles;
   }
   // lauum = true: the tiles of K^-1 = X^T X (lml.rs:62) follow the recursion in the same queue (whole matrix only)
   // rl = true: right-looking tile Cholesky + recursive inverse of the factor (build_rl) instead of the recursion that
@@ -133,7 +133,6 @@ class DagBuilder {
   bool big128_acc_ = false;  // ... also with beta = 1 (the old values fetched in the epilogue)
   bool rl_prog_ = false;     // right-looking plan: row-progressive inverse and K^-1 (rl_progressive)
   int prog_unear_ = -1, prog_knear_ = -1;  // single rows at the end of the U / K^-1 range lists (-1: rl_near_)
-  int prog_ratio_ = 0;       // 0: rl_groups' ranges (aligned powers of two); >= 2: ranges growing by this factor from the end
   bool prog_small_ = false;  // 64x64 tiles for the rows of X and the last U updates before a row (measured: no gain, more tasks)
   bool rl_chain32_ = true;   // right-looking plan: the two products between consecutive diagonal blocks as 32x64 one-shot tiles
   DagPlan plan_;
@@ -551,25 +550,8 @@ class DagBuilder {
     std::vector<DagGate> rowfin(nb), uprev(nb);
     std::vector<std::vector<std::pair<int, int>>> ugroups(nb);
     const int UNEAR = prog_unear_ >= 0 ? prog_unear_ : NEAR, KNEAR = prog_knear_ >= 0 ? prog_knear_ : NEAR;
-    // ranges of [0, n) counted from the END: `near` single rows, then ranges growing by the factor prog_ratio_ (3, 12, 48 ... for
-    // 4), the rest in one piece -- unaligned, unlike rl_groups (prog_ratio_ = 0: rl_groups' aligned powers of two)
-    auto ranges_from_end = [&](int n, int near) {
-      std::vector<std::pair<int, int>> out;
-      int b = n;
-      for (int q = 0; q < near && b > 0; ++q) { out.push_back({b - 1, b}); --b; }
-      int len = std::max(1, prog_ratio_ - 1);
-      while (b > 0) {
-        int a = std::max(0, b - len);
-        if (a < len / 2 + 1) a = 0;  // do not leave a sliver at the front
-        out.push_back({a, b});
-        b = a;
-        len *= prog_ratio_;
-      }
-      std::reverse(out.begin(), out.end());
-      return out;
-    };
-    for (int i = 1; i < nb; ++i) ugroups[i] = prog_ratio_ >= 2 ? ranges_from_end(i, std::max(1, UNEAR)) : rl_groups(i, GROUP, UNEAR);
-    const std::vector<std::pair<int, int>> kgroups = prog_ratio_ >= 2 ? ranges_from_end(nb, std::max(1, KNEAR)) : rl_groups(nb, GROUP, KNEAR);
+    for (int i = 1; i < nb; ++i) ugroups[i] = rl_groups(i, GROUP, UNEAR);
+    const std::vector<std::pair<int, int>> kgroups = rl_groups(nb, GROUP, KNEAR);
     DagGate kprev;
     const double g0 = plan_.gflop;
     double g_lauum = 0, cu = 0;
@@ -785,39 +767,12 @@ class DagBuilder {
     }
     while (!running.empty()) { now = running.top().first; running.pop(); }
     if ((int)out.size() == nt) {
-      if (chain_bias_us_ > 0) {
-        // The queue is claimed IN ORDER: a chain task that becomes ready while entries in front of it are still unclaimed waits
-        // for every one of them to be claimed first (a full chip frees a workgroup every ~0.4 us).  Move the chain's tasks
-        // (diagonal blocks, the 32x64 tiles between them) forward by chain_bias_us_ of simulated time -- a workgroup then claims
-        // them early and waits for their dependencies instead -- but never in front of a task they depend on (the order stays
-        // topological: key(task) > key(every task that bumps a counter it waits for)).
-        std::vector<double> key(nt, 0.0), ckey(nc, -1e30);
-        for (int pos = 0; pos < nt; ++pos) {
-          const int i = out_idx[pos];
-          const DagTask& t = plan_.tasks[i];
-          const bool chain = t.kind == DAG_LEAF || t.kind == DAG_GEMM_32x64;
-          double k = start[i] - (chain ? chain_bias_us_ : 0.0);
-          for (int w = 0; w < t.nwait; ++w) k = std::max(k, ckey[t.wcnt[w]] + 1e-6);
-          key[i] = k;
-          for (int q = 0; q < DAG_MAXSIG; ++q)
-            if (t.sig[q] != DAG_NOSIG) ckey[t.sig[q]] = std::max(ckey[t.sig[q]], k);
-        }
-        std::vector<int> perm(nt);
-        for (int pos = 0; pos < nt; ++pos) perm[pos] = pos;
-        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[out_idx[a]] < key[out_idx[b]]; });
-        std::vector<DagTask> re;
-        re.reserve(nt);
-        for (int pos = 0; pos < nt; ++pos) re.push_back(out[perm[pos]]);
-        out.swap(re);
-      }
       plan_.tasks.swap(out);
       plan_.sim_us = now;
     }
   }
-  double chain_bias_us_ = 0.0;
 
  public:
-  void set_chain_bias(double us) { chain_bias_us_ = us; }
   void set_big128(bool on, bool with_acc = false) { big128_ = on; big128_acc_ = on && with_acc; }
 };
 

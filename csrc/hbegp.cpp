@@ -691,7 +691,7 @@ struct Problem : ProblemBase {
                                    // `extend` repeats a fit's evaluation bit for bit.
                                    env_int("HBEGP_DAG_PROG", np / NB <= DAG_PROG_MAX_BLOCKS ? 1 : 0),
                                    env_int("HBEGP_DAG_PROG_UNEAR", -1), env_int("HBEGP_DAG_PROG_KNEAR", -1), env_int("HBEGP_DAG_PROG_SMALL", 0),
-                                   env_int("HBEGP_DAG_PROG_RATIO", 0), env_int("HBEGP_DAG_CHAIN_BIAS", 0),
+                                   0, 0,  // (round 4: geometric ranges, chain tasks moved forward in the queue -- measured, no gain, removed)
                                    // 128x128 tiles for the deep products without beta = 1 when several slots share the chip (throughput: half the
                                    // tasks, fewer fragment reads per MFMA): three-run fits M f64 1.727 -> 1.740, M f32 2.64 -> 2.77, C4 0.233 ->
                                    // 0.245; one evaluation alone gets SLOWER (fewer, longer tasks on 256 workgroups: n=4096 2.08 -> 2.22 ms), so
@@ -712,8 +712,7 @@ struct Problem : ProblemBase {
         if (!cached) {
           DagBuilder builder(key[1], key[2], key[3], key[4] != 0, key[5]);
           builder.set_rl(key[9], key[10], key[11] != 0, key[12] != 0);
-          builder.set_rl_progressive(key[13] != 0, key[14], key[15], key[16] != 0, key[17]);
-          builder.set_chain_bias((double)key[18]);
+          builder.set_rl_progressive(key[13] != 0, key[14], key[15], key[16] != 0);
           builder.set_big128(key[19] != 0, key[19] >= 2);
           cached = std::make_shared<const DagPlan>(builder.build(0, np / NB, dag_lauum_, dag_rl_));
           std::lock_guard<std::mutex> lk(cache_mu);
@@ -1007,70 +1006,9 @@ struct Problem : ProblemBase {
       if (tm) tm->end();
       return;
     }
-    static const int big_env = env_int("HBEGP_NBIG", 1 << 20);  // measured at n=4096: 8 -> 3.55 ms, 4 -> 3.56, off (binary recursion only) -> 3.43
-    const int big = std::max(1, big_env);
-    const int nbb = (nb + big - 1) / big;
-    if (nbb <= 1 || refine_) {
-      chol_inv_rec(s, di, 0, nb, tm);
-      return;
-    }
-    GemmOp base{};
-    base.lda = base.ldb = base.ldc = np;
-    for (int k = 0; k < nbb; ++k) {
-      const int lo = k * big, hi = std::min(nb, lo + big);
-      chol_inv_rec(s, di, lo, hi, tm);
-      if (hi >= nb) break;
-      {
-        // T[:, k] = A[:, k] * X_kk^T for every block row below  -> W2
-        GemmLaunch g{};
-        g.nops = 1;
-        GemmOp& op = g.op[0];
-        op = base;
-        op.A = s.W1; op.B = s.W2; op.C = s.W2;
-        op.ci0 = hi; op.mi = nb - hi; op.cj0 = lo; op.nj = hi - lo;
-        op.k0 = lo; op.k1 = hi; op.klim = 1; op.maskB = 1;
-        gemm(s, di, g, tm, PhaseTimer::GEMM);
-      }
-      {
-        // trailing update: A[i,j] -= T[i,k] T[j,k]^T, k < j <= i (lower)
-        GemmLaunch g{};
-        g.nops = 1;
-        GemmOp& op = g.op[0];
-        op = base;
-        op.A = s.W2; op.B = s.W2; op.C = s.W1;
-        op.ci0 = hi; op.cj0 = hi; op.mi = nb - hi; op.nj = nb - hi; op.c_lower = 1;
-        op.k0 = lo; op.k1 = hi; op.alpha_neg = 1; op.beta_one = 1;
-        gemm(s, di, g, tm, PhaseTimer::GEMM);
-      }
-    }
-    // off-diagonal blocks of X above the big-block level: X21 = -X22 * (T * X11), bottom-up over a binary tree of big blocks
-    for (int span = 1; span < nbb; span *= 2) {
-      std::vector<std::array<int, 3>> nodes;  // (lo, mid, hi) in 128-blocks
-      for (int a = 0; a + span < nbb; a += 2 * span)
-        nodes.push_back({a * big, std::min(nb, (a + span) * big), std::min(nb, (a + 2 * span) * big)});
-      for (size_t n0 = 0; n0 < nodes.size(); n0 += MAXOPS) {
-        const int cnt = (int)std::min<size_t>(MAXOPS, nodes.size() - n0);
-        GemmLaunch gu{}, gx{};
-        gu.nops = gx.nops = cnt;
-        for (int q = 0; q < cnt; ++q) {
-          const int lo = nodes[n0 + q][0], mid = nodes[n0 + q][1], hi = nodes[n0 + q][2];
-          GemmOp& u = gu.op[q];  // U = T * X11 -> W1[2,1]
-          u = base;
-          u.A = s.W2; u.B = s.W2; u.C = s.W1;
-          u.a_kmajor = 0; u.b_kmajor = 1;
-          u.ci0 = mid; u.mi = hi - mid; u.cj0 = lo; u.nj = mid - lo;
-          u.k0 = lo; u.k1 = mid; u.klim = 2; u.maskB = 1;
-          GemmOp& x = gx.op[q];  // X21 = -X22 * U -> W2[2,1]
-          x = base;
-          x.A = s.W2; x.B = s.W1; x.C = s.W2;
-          x.a_kmajor = 0; x.b_kmajor = 1;
-          x.ci0 = mid; x.mi = hi - mid; x.cj0 = lo; x.nj = mid - lo;
-          x.k0 = mid; x.k1 = hi; x.klim = 3; x.maskA = 1; x.alpha_neg = 1;
-        }
-        gemm(s, di, gu, tm, PhaseTimer::GEMM);
-        gemm(s, di, gx, tm, PhaseTimer::GEMM);
-      }
-    }
+    // (round 1: a right-looking sweep over 512- / 1024-wide big blocks in front of the recursion -- 3.55 vs 3.43 ms per evaluation at
+    // n = 4096, removed in round 5)
+    chol_inv_rec(s, di, 0, nb, tm);
   }
 
   void small_eval(Slot<T>& s, size_t di, int target, int mode) {
@@ -2489,8 +2427,7 @@ int hbegp_debug_dag_plan(int nblocks, int bk, int small_h, int nwg, int fine, in
   if (nblocks < 1 || (bk != 16 && bk != 32) || small_h < 0 || nwg < 0) return fail(HBEGP_EINVAL, "bad argument");
   GUARD_BEGIN
   DagBuilder builder(bk, small_h, nwg, (fine & 1) != 0);
-  builder.set_rl_progressive((fine & 16) != 0, -1, -1, false, getenv("HBEGP_DAG_PROG_RATIO") ? atoi(getenv("HBEGP_DAG_PROG_RATIO")) : 0);
-  builder.set_chain_bias(getenv("HBEGP_DAG_CHAIN_BIAS") ? atof(getenv("HBEGP_DAG_CHAIN_BIAS")) : 0.0);
+  builder.set_rl_progressive((fine & 16) != 0, -1, -1, false);
   builder.set_big128(getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) != 0, getenv("HBEGP_DAG_BIG128") && atoi(getenv("HBEGP_DAG_BIG128")) >= 2);
   // bit 1: unused (rounds 2-4: kernel-matrix tiles and alpha / lml reductions as tasks too); bit 2: the K^-1 = X^T X tiles behind
   // the recursion; bit 3: the right-looking plan; bit 4: its row-progressive inverse and K^-1

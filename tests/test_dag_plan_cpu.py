@@ -158,12 +158,3 @@ def test_plans_with_128x128_tiles_are_sound(nb, monkeypatch):
     if nb >= 8:
         _, big = plan(nb, 16, 4, 96, 1 | 4 | 8)
         assert big["ntasks"] < base["ntasks"]
-
-
-def test_chain_bias_keeps_the_queue_topological(monkeypatch):
-    # HBEGP_DAG_CHAIN_BIAS moves the chain's tasks forward in the queue, never in front of a task they depend on
-    for bias in ("5", "20", "200"):
-        monkeypatch.setenv("HBEGP_DAG_CHAIN_BIAS", bias)
-        for nb, fine in ((16, 1 | 4 | 8 | 16), (32, 1 | 4 | 8), (9, 1 | 4 | 8)):
-            rc, info = plan(nb, 16, 4, 96, fine)
-            assert rc == 0, (bias, nb, info["err"])

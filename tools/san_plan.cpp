@@ -13,14 +13,12 @@ int main() {
         for (int nwg : {0, 3, 96, 256}) {
           DagBuilder b(bk, rl ? 4 : 8, nwg, true, 1);
           b.set_rl(32, 1, nb % 2 == 0);
-          b.set_rl_progressive(rl != 0 && nb % 3 != 0, -1, -1, nb % 2 == 1, nb % 5 == 0 ? 3 : 0);  // two thirds of the right-looking plans: row-progressive inverse
+          b.set_rl_progressive(rl != 0 && nb % 3 != 0, -1, -1, nb % 2 == 1);  // two thirds of the right-looking plans: row-progressive inverse
           b.set_big128(nb % 4 < 2);
-          b.set_chain_bias(nb % 7 == 0 ? 15.0 : 0.0);
           DagPlan p = b.build(0, nb, true, rl != 0);
           if (p.tasks.empty()) { if (nb >= 2) ++bad; continue; }
           if (nb <= 24 && nwg == 96) { const std::string why = dag_plan_validate(p, nb); if (!why.empty()) { printf("nb=%d rl=%d: %s\n", nb, rl, why.c_str()); ++bad; } }
         }
-  // full mode
   // optimiser: slanted plane (gradmin.rs:75-101)
   double x[2] = {0.5, -0.3}, lo[2] = {-2, -2}, hi[2] = {2, 2};
   Objective f = [](const double* v, double* g) { g[0] = 1; g[1] = 1; return v[0] + v[1]; };
