@@ -325,7 +325,7 @@ def roofline_block(gpr, ctx, X, y, theta, nslots, ms_per_step, n_evals, extra_fl
     traffic, traffic_note = None, None
     if pmc_ok and is_dag:
         try:
-            src = "r04_pmc_3slot.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_pmc_3slot.json")) else "r03_pmc_3slot.json"
+            src = next(f for f in ("r05_pmc_3slot.json", "r04_pmc_3slot.json", "r03_pmc_3slot.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", src)))
             pmc = pmc.get("kernels", pmc)
             key = [k for k in pmc if "dag_kernel" in k]
