@@ -32,13 +32,13 @@
 #ifndef DAG_F64_KMUL
 #define DAG_F64_KMUL 1
 #endif
-// Stage-loop form per tile shape (dag_gemm_tile): 0 = round 2-4 (a stage's fragments in registers, reads / loads / stores in
-// clumps), 1 = round 5 (one k-step's fragments double-buffered, every non-MFMA instruction in the shadow of an MFMA).
+// Stage-loop form per tile shape (dag_gemm_tile): 0 = the shipped loop (a stage's fragments in registers, reads / loads / stores in
+// clumps); 1 = one k-step's fragments double-buffered, every non-MFMA instruction in the shadow of an MFMA; 2 = form 1 with three
+// register sets (loads three stages ahead).  Forms 1 and 2 are round 5's experiments: bitwise equal, +1.6 % / -4 % on the tile
+// alone, -0.5 % / -4 % in the fit -- NOT in the product build (these defaults), kept as compile-time forms
+// for tools/tile_ubench.hip, which also switches parts of form 1 off (PIPE = 1 + 16 * ABL) to price the loop's data path.
 #ifndef DAG_PIPE_128x128
 #define DAG_PIPE_128x128 0
-#endif
-#ifndef DAG_PIPE_F32_128x128
-#define DAG_PIPE_F32_128x128 0  /* f32: form 0 keeps 48 fragment registers beside the fp64 chunk totals and spills (round 4: 4 VGPRs, 32 B scratch) */
 #endif
 #ifndef DAG_PIPE_128x64
 #define DAG_PIPE_128x64 0
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(512, 2) dag_kernel(DagLaunch g) {
       } else if (kind == DAG_GEMM_64x64) {
         dag_gemm_tile<T, 64, 64, DAG_PIPE_64x64>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_128x128) {
-        dag_gemm_tile<T, 128, 128, (sizeof(T) == 4 ? DAG_PIPE_F32_128x128 : DAG_PIPE_128x128)>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
+        dag_gemm_tile<T, 128, 128, DAG_PIPE_128x128>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), static_cast<T*>(g.Kinv), g.ld, smem_raw, pull, fetch, inner_stamp);
       } else if (kind == DAG_GEMM_32x64) {
         dag_gemm_tile_chain<T>(flags, row0, col0, kbeg, kend, W1, W2, static_cast<T*>(g.W3), g.ld, smem_raw, pull, fetch);
       }
