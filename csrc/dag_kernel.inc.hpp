@@ -33,10 +33,12 @@
 #define DAG_F64_KMUL 1
 #endif
 // Stage-loop form per tile shape (dag_gemm_tile): 0 = the shipped loop (a stage's fragments in registers, reads / loads / stores in
-// clumps); 1 = one k-step's fragments double-buffered, every non-MFMA instruction in the shadow of an MFMA; 2 = form 1 with three
-// register sets (loads three stages ahead).  Forms 1 and 2 are round 5's experiments: bitwise equal, +1.6 % / -4 % on the tile
-// alone, -0.5 % / -4 % in the fit -- NOT in the product build (these defaults), kept as compile-time forms
-// for tools/tile_ubench.hip, which also switches parts of form 1 off (PIPE = 1 + 16 * ABL) to price the loop's data path.
+// clumps); 1 = one k-step's fragments double-buffered, every non-MFMA instruction in the shadow of an MFMA.  Form 1 is round 5's
+// experiment: bitwise equal, +1.6 % on the tile alone, -0.5 % in the fit -- NOT in the product build (these
+// defaults), kept as a compile-time form for tools/tile_ubench.hip, which also switches parts of it off (PIPE = 1 + 16 * ABL) to
+// price the loop's data path.  Two more forms were built on it, measured and removed (commit 392ba09 has them): three register
+// sets with loads three stages ahead (88.3 % of the MFMA rate alone, -4 % in the fit) and an LDS-DMA ring (global_load_lds into
+// unpadded, source-swizzled stage images: 80-83 %).
 #ifndef DAG_PIPE_128x128
 #define DAG_PIPE_128x128 0
 #endif
@@ -111,7 +113,6 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   const size_t a_qs = (size_t)a_rpp * ld, b_qs = (size_t)b_rpp * ld;
 
   vec_t ra0[NCHA], rb0[NCHB], ra1[NCHA], rb1[NCHB];
-  vec_t ra2[(PIPE & 15) == 2 ? NCHA : 1], rb2[(PIPE & 15) == 2 ? NCHB : 1];  // PIPE 2: a third set, loads three stages ahead
   auto load_stage = [&](vec_t (&ra)[NCHA], vec_t (&rb)[NCHB]) {
 #pragma unroll
     for (int q = 0; q < NCHA; ++q) ra[q] = *reinterpret_cast<const vec_t*>(pA + q * a_qs);
@@ -143,11 +144,7 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
   const bool accum = (flags & DAGF_ACC) != 0;
   const bool cinit = !NOACC && sizeof(T) == 8 && (flags & DAGF_CINIT) != 0;  // the old values start the accumulation (engine.hpp)
   constexpr bool PREFETCH_C = TA == 64 || (sizeof(T) == 8 && DAG_F64_KMUL > 1);
-  // PIPE 3 (LDS-DMA ring, below): NS3 unpadded stage images of (TA + TB) rows x 128 bytes
-  constexpr int NS3 = TB == 128 ? 4 : 3;
-  constexpr int SBYTES3 = (TA + TB) * 128;
-  constexpr int STASH_OFF = (PIPE & 15) == 3 ? NS3 * SBYTES3 / (int)sizeof(T)
-                                             : 2 * (G::LDSA + G::LDSB);  // in elements of T, behind the stage buffers
+  constexpr int STASH_OFF = 2 * (G::LDSA + G::LDSB);  // in elements of T, behind [A buf0 | A buf1 | B buf0 | B buf1]
   static_assert(NOACC || PREFETCH_C || (size_t)(STASH_OFF + TA * TB) * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stash must fit in front of the control words");
   static_assert((size_t)STASH_OFF * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "the stage buffers must fit in front of the control words");
   T cold[PREFETCH_C ? TMA : 1][PREFETCH_C ? TMB : 1][4];
@@ -329,228 +326,6 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
       pull();
       fetch();
     }
-  } else if constexpr ((PIPE & 15) == 3) {
-    // PIPE 3 (round 5, experiment): the registers leave the data path.  Operands go global -> LDS by LDS-DMA (global_load_lds,
-    // 16 bytes per lane, 1 KiB per wave instruction) into a ring of NS3 UNPADDED stage images; the bank conflicts an unpadded
-    // image would have are removed by an XOR swizzle applied to the SOURCE address (the DMA's destination is lane-linear) and
-    // again to the fragment reads:
-    //   operand stored [outer][k] (rows of 16 k = 128 bytes, 8 chunks of 16 bytes): chunk' = chunk ^ ((row >> 1) & 7)
-    //   operand stored [k][outer] (rows of T outer values):                          chunk' = chunk ^ ((k & 1) << 3)
-    // (a 32-lane group of a ds_read_b64 then touches every bank once).  NS3 - 1 stages are in flight; a wave waits for ITS
-    // pieces of stage s+1 (counted vmcnt) before the barrier that ends interval s.  Fragments as in PIPE 1 (one k-step double
-    // buffered, reads in the shadows of the MFMAs).  Same k-ascending chain per element: same bits.
-    static_assert(sizeof(T) == 8 && TA == 128 && (TB == 128 || TB == 64), "LDS-DMA stage images: f64, 128-row tiles");
-    static_assert(NK % 2 == 0 && NK >= 2, "k-step k lives in fragment set k & 1 across stage boundaries");
-    constexpr int NS = NS3, SBYTES = SBYTES3, ABYTES = TA * 128;
-    constexpr int ABL3 = PIPE >> 4;  // tools/tile_ubench only (wrong results): 1 = no DMA in the loop, 8 = no fragment reads
-    constexpr int NPA = TA / 8, NPB = TB / 8, PER = (NPA + NPB) / 8;  // 1 KiB pieces per stage: A, B; per wave
-    static_assert((NPA + NPB) % 8 == 0, "the pieces of a stage are dealt evenly to the eight waves");
-    static_assert(NOACC || PREFETCH_C || (size_t)NS * SBYTES + (size_t)TA * TB * sizeof(T) <= (size_t)DAG_LDS_CTL_OFF, "ring + stash fit in front of the control words");
-    static_assert((size_t)NS * SBYTES <= (size_t)DAG_LDS_CTL_OFF, "the ring fits in front of the control words");
-    constexpr int NF = TMA + TMB, NM = TMA * TMB;
-    constexpr int RPM = (NF + NM - 1) / NM;
-    const int kq = lane >> 4;
-    // this wave's pieces: per-lane source pointer (advanced by gstep per stage), LDS byte offset inside a slot
-    const T* gsrc[PER];
-    size_t gstep[PER];
-    int ldsoff[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int q = wave + 8 * i;  // wave-uniform
-      if (q < NPA) {
-        if (!akm) {
-          const int r = 8 * q + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-          gsrc[i] = Ag + (size_t)(row0 + r) * ld + kbeg + 2 * c;
-          gstep[i] = BK;
-        } else {  // one k row of TA = 128 outer values per piece
-          const int c = lane ^ ((q & 1) << 3);
-          gsrc[i] = Ag + (size_t)(kbeg + q) * ld + row0 + 2 * c;
-          gstep[i] = (size_t)BK * ld;
-        }
-        ldsoff[i] = q * 1024;
-      } else {
-        const int qb = q - NPA;
-        if (!bkm) {
-          const int r = 8 * qb + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-          gsrc[i] = Bg + (size_t)(col0 + r) * ld + kbeg + 2 * c;
-          gstep[i] = BK;
-        } else if (TB == 128) {
-          const int c = lane ^ ((qb & 1) << 3);
-          gsrc[i] = Bg + (size_t)(kbeg + qb) * ld + col0 + 2 * c;
-          gstep[i] = (size_t)BK * ld;
-        } else {  // two k rows of 64 outer values per piece
-          const int k = 2 * qb + (lane >> 5), c = (lane & 31) ^ ((k & 1) << 3);
-          gsrc[i] = Bg + (size_t)(kbeg + k) * ld + col0 + 2 * c;
-          gstep[i] = (size_t)BK * ld;
-        }
-        ldsoff[i] = ABYTES + qb * 1024;
-      }
-    }
-    typedef __attribute__((address_space(3))) char lds_char;
-    typedef const __attribute__((address_space(1))) void gvoid;
-    lds_char* sm3 = (lds_char*)smem_raw;
-    auto dma_stage = [&](int slot) {
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        __builtin_amdgcn_global_load_lds((gvoid*)gsrc[i], (__attribute__((address_space(3))) void*)(sm3 + slot * SBYTES + ldsoff[i]), 16, 0, 0);
-        gsrc[i] += gstep[i];
-      }
-    };
-    // LDS addresses of this lane's fragment elements (slot 0), per k-step; each moves on by one slot right after it has been read
-    // (a VALU add in the shadow of an MFMA -- as a block behind the stage barrier the 24 adds cost the loop 5 %)
-    typedef const __attribute__((address_space(3))) T lds_T;
-    lds_T* fad[NK][NF];
-#pragma unroll
-    for (int k4 = 0; k4 < NK; ++k4) {
-#pragma unroll
-      for (int a = 0; a < TMA; ++a) {
-        const int o = wm * (TA / G::WM) + a * 16 + (lane & 15);
-        const int off = !akm ? o * 128 + ((((2 * k4) ^ ((kq >> 1) ^ ((o >> 1) & 7)))) << 4) + (kq & 1) * 8
-                             : (4 * k4 + kq) * (TA * 8) + ((((o >> 1) ^ ((kq & 1) << 3))) << 4) + (o & 1) * 8;
-        fad[k4][a] = reinterpret_cast<lds_T*>(sm3 + off);
-      }
-#pragma unroll
-      for (int b2 = 0; b2 < TMB; ++b2) {
-        const int o = wn * (TB / G::WN) + b2 * 16 + (lane & 15);
-        const int off = ABYTES + (!bkm ? o * 128 + ((((2 * k4) ^ ((kq >> 1) ^ ((o >> 1) & 7)))) << 4) + (kq & 1) * 8
-                                       : (4 * k4 + kq) * (TB * 8) + ((((o >> 1) ^ ((kq & 1) << 3))) << 4) + (o & 1) * 8);
-        fad[k4][TMA + b2] = reinterpret_cast<lds_T*>(sm3 + off);
-      }
-    }
-    T fr[2][NF];
-    int delta_el = 0;  // uniform: elements from this interval's slot to the next one's
-    auto read_frag = [&](int set, int k4, int i) {
-      fr[set][i] = *fad[k4][i];
-      fad[k4][i] += delta_el;
-    };
-    auto group = [&](int ms, bool rd, int rk) {
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        acc[i / TMB][i % TMB] = C::mfma(fr[ms][i / TMB], fr[ms][TMA + i % TMB], acc[i / TMB][i % TMB]);
-        if (rd) {
-#pragma unroll
-          for (int q = 0; q < RPM; ++q)
-            if (i * RPM + q < NF) read_frag(ms ^ 1, rk, i * RPM + q);
-        }
-      }
-    };
-    auto pin = [&](bool rd) {
-#pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (rd && i * RPM < NF) {
-          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, RPM, 0);
-        }
-      }
-    };
-    // interval s: stage s sits in slot `rslot` (where fad points); the DMA of stage s + NS - 1 goes to slot `dslot`
-    auto interval = [&](bool g0, bool do_dma, int dslot, int younger, int rslot_now) {
-      delta_el = (rslot_now + 1 == NS ? -(NS - 1) : 1) * (SBYTES / (int)sizeof(T));
-      __builtin_amdgcn_sched_barrier(0);
-      if (do_dma && !(ABL3 & 1)) dma_stage(dslot);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g0) {
-        group((NK - 1) & 1, !(ABL3 & 8), 0);
-        pin(true);
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < NF; ++i) read_frag(0, 0, i);
-        if constexpr ((ABL3 & 8) != 0) {
-#pragma unroll
-          for (int i = 0; i < NF; ++i) read_frag(1, 1, i);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k4 = 0; k4 + 1 < NK; ++k4) {
-        group(k4 & 1, !(ABL3 & 8), k4 + 1);
-        pin(true);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // stage s + 1 is complete and visible behind this barrier: every wave's own pieces of it have landed (`younger` stages
-      // issued after it may still be in flight), and this interval's fragment reads have returned (the next interval's DMA
-      // overwrites the slot they came from)
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    static_assert(NS - 2 <= 2, "interval() knows the waits for at most two younger stages");
-    if (nstages > 0) {
-      // the old values of a beta = 1 tile first (ordinary loads: their wait would drain DMAs issued before them)
-      T cst[(!PREFETCH_C && !NOACC) ? TMA : 1][(!PREFETCH_C && !NOACC) ? TMB : 1][4];
-      bool stash = false;
-      if constexpr (!PREFETCH_C && !NOACC) {
-        if (accum) {
-          const int er0p = row0 + wm * (TA / G::WM), ec0p = col0 + wn * (TB / G::WN) + (lane & 15);
-#pragma unroll
-          for (int a = 0; a < TMA; ++a)
-#pragma unroll
-            for (int b = 0; b < TMB; ++b)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) cst[a][b][r] = Cg[(size_t)(er0p + a * 16 + C::crow(lane, r)) * ld + ec0p + b * 16];
-          stash = true;
-          if (cinit) {
-            stash = false;
-#pragma unroll
-            for (int a = 0; a < TMA; ++a)
-#pragma unroll
-              for (int b = 0; b < TMB; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[a][b][r] = cst[a][b][r];
-          }
-          if (stash) {
-#pragma unroll
-            for (int a = 0; a < TMA; ++a)
-#pragma unroll
-              for (int b = 0; b < TMB; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lds[STASH_OFF + ((a * TMB + b) * 4 + r) * NT + t] = cst[a][b][r];
-          }
-        }
-      }
-      const int npro = nstages < NS - 1 ? nstages : NS - 1;
-      for (int j = 0; j < npro; ++j) dma_stage(j);
-      // stage 0 has landed once at most npro - 1 younger stages are in flight
-      if (npro - 1 >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-      else if (npro - 1 == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-#ifdef DAG_STAMP_INNER
-      unsigned long long st1 = 0;
-      if (inner && t == 0) st1 = __builtin_amdgcn_s_memrealtime();
-#endif
-      int s = 0, rslot = 0;
-      bool g0 = false;
-      auto step_slot = [&]() { rslot = rslot + 1 == NS ? 0 : rslot + 1; };
-      for (; s + NS - 1 < nstages; ++s) {  // steady state: a stage to fetch, NS - 2 younger stages behind stage s + 1
-        interval(g0, true, rslot == 0 ? NS - 1 : rslot - 1, NS - 2, rslot);
-        g0 = true;
-        step_slot();
-      }
-      bool hooked_pull = false, hooked_fetch = false;
-      for (; s < nstages; ++s) {  // the last NS - 1 stages: nothing left to fetch
-        const int left = nstages - s;  // 1 .. NS - 1
-        if (!hooked_pull) { pull(); hooked_pull = true; }
-        if (left == 1 && !hooked_fetch) { fetch(); hooked_fetch = true; }
-        interval(g0, false, 0, left - 2 > 0 ? left - 2 : 0, rslot);
-        g0 = true;
-        step_slot();
-      }
-      if (!hooked_fetch) fetch();
-      group((NK - 1) & 1, false, 0);  // the last k-step of the last stage
-      kabs += BK * nstages;
-#ifdef DAG_STAMP_INNER
-      if (inner && t == 0) *inner = ((st1 & 0xffffffffull) << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);
-#endif
-    } else {
-      pull();
-      fetch();
-    }
   } else {
     // PIPE 1 (round 5): the stage loop with every wave's LDS reads, global loads and LDS stores dealt one by one into the
     // shadows of its own MFMAs.  Why: the two waves of a SIMD share one fp64 MFMA pipe and the pipe serves the older wave
@@ -631,9 +406,6 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
     if (nstages > 0) {
       load_stage(ra0, rb0);
       if (nstages > 1) load_stage(ra1, rb1);
-      if constexpr ((PIPE & 15) == 2) {
-        if (nstages > 2) load_stage(ra2, rb2);
-      }
       if constexpr (!PREFETCH_C && !NOACC) {
         if (accum) {  // old values of the output tile -> LDS stash (as PIPE 0)
           T cst[TMA][TMB][4];
@@ -678,40 +450,6 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
 #endif
       int s = 0;
       bool g0 = false;
-      if constexpr ((PIPE & 15) == 2) {
-        // three register sets: stage s is loaded into set s % 3 three intervals before it is read, interval s stores stage s + 1
-        int cur = 0;
-        for (; s + 5 < nstages; s += 3) {
-          interval(cur, g0, true, ra0, rb0, true, ra1, rb1);
-          g0 = true;
-          interval(cur ^ 1, true, true, ra1, rb1, true, ra2, rb2);
-          interval(cur, true, true, ra2, rb2, true, ra0, rb0);
-          cur ^= 1;
-        }
-        const int left = nstages - s;  // 1..5; interval j of the tail: loads while j + 3 < left, stores while j + 1 < left
-        const int jp = left > 3 ? left - 3 : 0;  // first interval without a load: the next queue entry is claimed in front of it
-        if (jp == 0) pull();
-        if (left == 1) fetch();
-        interval(cur, g0, 3 < left, ra0, rb0, 1 < left, ra1, rb1);
-        if (left > 1) {
-          if (jp == 1) pull();
-          if (left == 2) fetch();
-          interval(cur ^ 1, true, 4 < left, ra1, rb1, 2 < left, ra2, rb2);
-        }
-        if (left > 2) {
-          if (jp == 2) pull();
-          if (left == 3) fetch();
-          interval(cur, true, false, ra2, rb2, 3 < left, ra0, rb0);
-        }
-        if (left > 3) {
-          if (left == 4) fetch();
-          interval(cur ^ 1, true, false, ra0, rb0, 4 < left, ra1, rb1);
-        }
-        if (left > 4) {
-          fetch();
-          interval(cur, true, false, ra1, rb1, false, ra2, rb2);
-        }
-      } else {
         for (; s + 3 < nstages; s += 2) {
           interval(0, g0, true, ra0, rb0, true, ra1, rb1);
           g0 = true;
@@ -728,7 +466,6 @@ __device__ __forceinline__ void dag_gemm_tile(int flags, int row0, int col0, int
           fetch();
           interval(0, true, false, ra0, rb0, false, ra1, rb1);
         }
-      }
       // the last k-step of the last stage
       group((NK - 1) & 1, false, 0, 0);
       kabs += BK;

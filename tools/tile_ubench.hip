@@ -81,9 +81,6 @@ int main(int argc, char** argv) {
       {"128x128 pipe0", 128, 128, run<double, 128, 128, 0>}, {"128x128 pipe1", 128, 128, run<double, 128, 128, 1>},
       {"128x64  pipe0", 128, 64, run<double, 128, 64, 0>},   {"128x64  pipe1", 128, 64, run<double, 128, 64, 1>},
       {"64x64   pipe0", 64, 64, run<double, 64, 64, 0>},     {"64x64   pipe1", 64, 64, run<double, 64, 64, 1>},
-      {"128x128 pipe3", 128, 128, run<double, 128, 128, 3>}, {"128x64  pipe3", 128, 64, run<double, 128, 64, 3>},
-      {"128x128 pipe3 no DMA in the loop (wrong results)", 128, 128, run<double, 128, 128, 3 + 16>},
-      {"128x128 pipe3 no fragment reads (wrong results)", 128, 128, run<double, 128, 128, 3 + 16 * 8>},
   };
   if (getenv("TILE_UBENCH_ABL")) {  // what each part of the loop costs beside the MFMAs (wrong results: the checks below will say so)
     vs = {
