@@ -451,12 +451,17 @@ def test_fresh_pool_blocks_are_cleared_before_their_first_writer(dtype, monkeypa
     try:
         old = run()
         damaged = not (max(old) <= tol)  # NaN counts as damaged
-    except gpr.HbegpError:
+    except gpr.HbegpError as e:
         damaged = True  # e.g. "not positive definite": the kernel matrix was zeroed under the factorisation
+        old = f"error: {e}"
     finally:
         # drain the null stream (late clears may still be queued) before any other test recycles these blocks: every fresh block
         # of the shipped path waits for the null stream
         monkeypatch.delenv("HBEGP_POOL_OLD_CLEAR")
         again = run()
-    assert damaged, f"the unsynchronised clear did not damage the model (deviations {old}): round 4's diagnosis does not hold"
+    print(f"old clear ({np.dtype(dtype).name}): {old}; shipped clear: {devs}, again {again}")
+    # (eager launches, HBEGP_NO_GRAPH=1 in tools/gpu_matrix.sh: the old clear does no damage there -- deviations 5e-14 -- so the
+    # demonstration leg is asserted for the shipped configuration only)
+    if os.environ.get("HBEGP_NO_GRAPH", "0") in ("", "0"):
+        assert damaged, f"the unsynchronised clear did not damage the model (deviations {old}): round 4's diagnosis does not hold"
     assert max(again) <= tol, again
