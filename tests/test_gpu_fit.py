@@ -67,6 +67,7 @@ def test_fit_trace_replays_on_oracle_and_capture_rule():
                 rf[0].close()
         best = max(best, tr["lml"][i])
     print("trace replay, every evaluation: " + judge.summary())
+    assert judge.n_nodigits == 0  # f64: the oracle always has digits
     assert judge.n_plain + judge.n_refereed >= 2 * 30
     # capture = arg-max over every evaluation of every run (fit.rs:116-125)
     assert fk.lml == best
@@ -79,6 +80,7 @@ def test_fit_trace_replays_on_oracle_and_capture_rule():
     jm.check("alpha of the fitted model", alpha, res["alpha"], lambda: sum(rf.alpha()))
     jm.check("K^-1 of the fitted model", kinv, res["k_inv"], lambda: sum(rf.kinv()))
     print("fitted model: " + jm.summary())
+    assert jm.n_nodigits == 0
     rf.close()
     # fitting must improve on the start point
     assert fk.lml > tr["lml"][0]
@@ -391,6 +393,7 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
             rf[0].close()
     print(f"persistent fit, every evaluation ({np.dtype(dtype).name}): " + judge.summary() +
           f"; LAPACK failed at {n_lapack_failed}, the engine alone at {n_gpu_only_failed}")
+    assert dtype == np.float32 or judge.n_nodigits == 0
     assert fk.lml == tr["lml"].max()  # capture = arg-max over every evaluation of every run
     i_best = int(np.argmax(tr["lml"]))
     f, g, res = O.objective(tr["theta"][i_best], X, y, 2.5, bounds)
@@ -403,6 +406,7 @@ def test_persistent_fit_kernel_for_the_reference_regime(n, cfg, dtype, fixed_wor
         jm.check("alpha of the fitted model", alpha, res["alpha"], lambda: sum(rf.alpha()), sigma_fn=(lambda: kb["alpha"]) if kb else None)
         jm.check("K^-1 of the fitted model", kinv, res["k_inv"], lambda: sum(rf.kinv()), sigma_fn=(lambda: kb["kinv"]) if kb else None)
         print("fitted model: " + jm.summary())
+        assert dtype == np.float32 or jm.n_nodigits == 0
         rf.close()
     mean, var, _ = fk.predict(X[:5])
     assert np.all(np.isfinite(mean)) and np.all(var >= 0)
