@@ -240,6 +240,9 @@ struct SmallFit {
   int maxeval, memory, fixed_work;
   double pgtol, ftol;
   SmallFitResult* res;       // device
+  SmallFitResult* hres;      // pinned host copy of *res, written at the end of the run (null: none) ...
+  unsigned long long* hdone; // ... followed, behind a system-scope fence, by 1 in this pinned word: the host thread that owns the
+                             // run polls it -- the launch may carry other fits' runs (hbegp.cpp: SmallBatcher) and need not be over
   double* trace_theta;       // [trace_cap][p] (device; may be null with trace_cap = 0)
   double* trace_lml;         // [trace_cap]
   double* trace_grad;        // [trace_cap][p]

@@ -89,7 +89,9 @@ static std::atomic<int> g_live_ctx{0};  // the block pool is process-global: it 
 // exact size.  Recycled blocks hold finite numbers from their previous life, which is all the engine requires of
 // never-written regions (strict upper triangles).
 #include <chrono>
+#include <condition_variable>
 #include <map>
+#include <tuple>
 struct DevPool {
   std::mutex mu;
   std::map<std::pair<int, size_t>, std::vector<void*>> free_list;
@@ -235,7 +237,7 @@ static HostPool g_host_pool;
 // evaluation slots of a fit always get the same streams back (created first, on distinct queues), whatever a model's or the
 // block pool's stream does in between -- with ONE free list a fit's three slots got, every other fit, two streams of one queue
 // (measured: optimiser runs of config M 561 / 900 / 561 / 900 ms).
-enum { STREAM_SLOT = 0, STREAM_MODEL = 1 };
+enum { STREAM_SLOT = 0, STREAM_MODEL = 1, STREAM_BATCH = 2 };
 struct StreamPool {
   std::mutex mu;
   std::map<std::pair<int, int>, std::vector<hipStream_t>> free_list;
@@ -250,8 +252,20 @@ struct StreamPool {
       }
     }
     hipStream_t s = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
-    if (e != hipSuccess) throw HipError{e, "hipStreamCreateWithFlags (pool)", __LINE__};
+    hipError_t e;
+    static const bool batch_prio = env_int("HBEGP_BATCH_STREAM_PRIORITY", 1) != 0;
+    if (kind == STREAM_BATCH && batch_prio) {
+      // the runtime keeps a pool of hardware queues PER PRIORITY: a stream of another priority never shares its queue with the
+      // normal-priority streams of the fits -- whose copies and small kernels would otherwise wait for the ~10 ms persistent grid
+      // of a small-fit batch whenever they land on its queue
+      int least = 0, greatest = 0;
+      e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (e != hipSuccess) throw HipError{e, "hipDeviceGetStreamPriorityRange", __LINE__};
+      e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest);
+    } else {
+      e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    }
+    if (e != hipSuccess) throw HipError{e, "hipStreamCreate (pool)", __LINE__};
     return s;
   }
   void put(int dev, hipStream_t s, int kind = STREAM_SLOT) {  // the caller has synchronised it
@@ -271,6 +285,117 @@ struct StreamPool {
 static StreamPool g_stream_pool;
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Fits of up to 128 rows from several host threads share their launches.  An optimiser run of such a fit is one workgroup of a
+// persistent kernel (small_fit_kernel, ~10 ms); with a launch per fit the fits of different threads sit on different streams, HIP
+// maps streams onto a handful of hardware queues, and a stream that shares its queue with another fit's persistent kernel waits
+// for all of it (measured: 16 threads, 16 hardware queues: 560 fits/s where 16 / 10.5 ms = 1,500 would fit the chip; more
+// queues made it worse).  So: a thread that arrives with its runs joins the batch that is open for its (device, kernel) or opens
+// one; whoever opened it waits until no other thread is on its way (threads announce themselves when they enter the small-fit
+// path: SmallBatcher::arriving), at most 3 ms of a ~10 ms fit (HBEGP_SMALL_BATCH_US; measured at 16 threads: 0.3 ms 724, 1 ms 959, 3 ms
+// 1,113 fits/s -- under load a thread needs 2-3 ms to set its problem up), and launches all runs in ONE grid; every thread then polls the pinned words of its
+// OWN runs (SmallFit::hdone) -- it neither waits for the other fits of the launch nor synchronises a stream.  One thread alone
+// launches at once.  The workgroups of a launch do not depend on each other, so a run's bits do not depend on its company.
+struct SmallBatch {
+  std::vector<SmallFit> fits;
+  bool closed = false, launched = false;
+  int refs = 0;
+  std::exception_ptr err;  // launch failure: every participant rethrows it
+  void* fs_dev = nullptr;
+  size_t fs_bytes = 0;
+  hipStream_t stream = nullptr;
+  int dev = 0;
+};
+struct SmallBatcher {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<std::tuple<int, int, bool>, std::shared_ptr<SmallBatch>> open;  // (device id, nu2, f32)
+  std::atomic<int> arriving{0};  // threads inside the small-fit path that have not handed in their runs yet
+};
+static SmallBatcher g_small_batcher;
+struct SmallArrival {  // RAII: "I am on my way with runs"
+  bool counted = false;
+  void announce() { if (!counted) { g_small_batcher.arriving.fetch_add(1); counted = true; } }
+  void arrived() {
+    if (counted) {
+      g_small_batcher.arriving.fetch_sub(1);
+      counted = false;
+      g_small_batcher.cv.notify_all();
+    }
+  }
+  ~SmallArrival() { arrived(); }
+};
+static void small_batch_unref_locked(SmallBatch& b);
+// Hands in `mine` (runs of one fit on device `dev`); returns the batch once its grid has been launched.  The caller polls its runs'
+// SmallFit::hdone words and then calls small_batch_leave.  Throws if the launch failed.
+template <typename T>
+static std::shared_ptr<SmallBatch> small_batch_submit(int dev, int nu2, const std::vector<SmallFit>& mine, SmallArrival& arrival) {
+  SmallBatcher& B = g_small_batcher;
+  static const int window_us = env_int("HBEGP_SMALL_BATCH_US", 3000);
+  std::unique_lock<std::mutex> lk(B.mu);
+  const auto key = std::make_tuple(dev, nu2, sizeof(T) == 4);
+  std::shared_ptr<SmallBatch> b = B.open[key];
+  const bool leader = !b;
+  if (leader) {
+    b = std::make_shared<SmallBatch>();
+    b->dev = dev;
+    B.open[key] = b;
+  }
+  b->fits.insert(b->fits.end(), mine.begin(), mine.end());
+  ++b->refs;
+  arrival.arrived();  // (notifies: a leader waiting for the stragglers looks again)
+  if (leader) {
+    if (window_us > 0)
+      B.cv.wait_for(lk, std::chrono::microseconds(window_us), [&] { return B.arriving.load() == 0; });
+    b->closed = true;
+    B.open.erase(key);
+    lk.unlock();
+    try {
+      HIPCHECK(hipSetDevice(dev));
+      b->fs_bytes = sizeof(SmallFit) * (size_t)round_up((int)b->fits.size(), 16);
+      bool fresh = false;
+      b->fs_dev = g_pool.get(dev, b->fs_bytes, &fresh);
+      b->stream = g_stream_pool.get(dev, STREAM_BATCH);
+      HIPCHECK(hipMemcpyAsync(b->fs_dev, b->fits.data(), sizeof(SmallFit) * b->fits.size(), hipMemcpyHostToDevice, b->stream));  // (the batch outlives the copy)
+      launch_small_fit<T>(static_cast<const SmallFit*>(b->fs_dev), (int)b->fits.size(), nu2, b->stream);
+      CHECK_LAUNCHES();
+    } catch (...) {
+      b->err = std::current_exception();
+    }
+    lk.lock();
+    b->launched = true;
+    B.cv.notify_all();
+  } else {
+    B.cv.wait(lk, [&] { return b->launched; });
+  }
+  if (b->err) {
+    std::exception_ptr e = b->err;
+    if (b->stream) (void)hipStreamSynchronize(b->stream);  // (a copy may have been queued before the launch failed)
+    small_batch_unref_locked(*b);
+    lk.unlock();
+    std::rethrow_exception(e);
+  }
+  return b;
+}
+static void small_batch_unref_locked(SmallBatch& b) {
+  if (--b.refs == 0) {  // every run of the grid is over (each participant saw its words, or waited for the stream)
+    if (b.fs_dev) g_pool.put(b.dev, b.fs_dev, b.fs_bytes);
+    if (b.stream) g_stream_pool.put(b.dev, b.stream, STREAM_BATCH);
+    b.fs_dev = nullptr;
+    b.stream = nullptr;
+  }
+}
+// `finished`: the caller has seen every one of its runs' hdone words (false: it gave up -- the grid is waited for here, its
+// workspaces are about to be released)
+static void small_batch_leave(const std::shared_ptr<SmallBatch>& b, bool finished) {
+  if (!b) return;
+  if (!finished && b->stream) {
+    (void)hipSetDevice(b->dev);
+    (void)hipStreamSynchronize(b->stream);
+  }
+  std::lock_guard<std::mutex> lk(g_small_batcher.mu);
+  small_batch_unref_locked(*b);
+}
 constexpr int DAG_PROG_MAX_BLOCKS = 20;  // right-looking plan: the inverse and K^-1 follow the chain row by row up to this many 128-blocks
 constexpr int DAG_MIN_BLOCKS_FIT = 6;   // evaluations (a fit's, `extend`'s, single ones) use the task queue from this many 128-blocks on
 
@@ -424,6 +549,7 @@ template <typename T>
 struct Slot {
   int dev = 0;
   hipStream_t stream = nullptr;
+  bool stream_adopted = false;  // a model built from this (temporary) problem keeps the stream: it goes back to the pool with the model
   T *W1 = nullptr, *W2 = nullptr, *Kinv[2] = {nullptr, nullptr}, *alpha[2] = {nullptr, nullptr};
   T* W3 = nullptr;  // f32 problems only: the Cholesky factor L (lower), kept for the refinement of the panel solves
   T *ldiag = nullptr, *wbuf = nullptr;
@@ -823,7 +949,7 @@ struct Problem : ProblemBase {
         for (int b = 0; b < 2; ++b) g_pool.put(s.dev, s.Kinv[b], nnb);
         g_pool.put(s.dev, s.small_slab, s.small_slab_bytes);
         g_host_pool.put(s.host_slab, s.host_slab_bytes);
-        g_stream_pool.put(s.dev, s.stream);  // synchronised above
+        if (!s.stream_adopted) g_stream_pool.put(s.dev, s.stream);  // synchronised above
       }
     }
     for (const Pooled& q : pooled_) g_pool.put(q.dev, q.p, q.bytes);  // features, targets, task queues, control words, schedule tables
@@ -1524,6 +1650,7 @@ struct hbegp_model {
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
   hipStream_t stream = nullptr;
+  int stream_kind = 1;  // StreamPool list the stream goes back to (STREAM_MODEL; STREAM_SLOT when adopted from the fit's problem)
   // predict scratch (grow-only)
   int cap_m = 0;
   void *Xs = nullptr, *Ks = nullptr, *Q = nullptr, *mean = nullptr, *var = nullptr;
@@ -1558,20 +1685,34 @@ struct hbegp_model {
     g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes);
     for (const Pooled& q : pooled) g_pool.put(dev, q.p, q.bytes);
     g_host_pool.put(sm_hin, sm_hin_bytes); g_host_pool.put(sm_hout, sm_hout_bytes);
-    g_stream_pool.put(dev, stream, STREAM_MODEL);  // synchronised above
+    g_stream_pool.put(dev, stream, stream_kind);  // synchronised above
   }
 };
 
+static bool model_adopts_stream() {
+  static const bool on = env_int("HBEGP_MODEL_OWN_STREAM", 0) == 0;
+  return on;
+}
 template <typename T>
 static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double* theta_clamped, double lml,
-                               bool w2_current = false, const double* params_linear = nullptr) {
+                               bool w2_current = false, const double* params_linear = nullptr, bool adopt_stream = false) {
   Slot<T>& s = prob.slots[di][si];
   HIPCHECK(hipSetDevice(s.dev));
   std::unique_ptr<hbegp_model> m(new hbegp_model());
   m->dev = s.dev; m->n = prob.n; m->d = prob.d; m->np = prob.np; m->nu2 = prob.nu2; m->is_f32 = prob.is_f32; m->lml = lml;
   m->theta.assign(theta_clamped, theta_clamped + prob.d + 2);
   const size_t nn = (size_t)prob.np * prob.np;
-  m->stream = g_stream_pool.get(m->dev, STREAM_MODEL);
+  // adopt_stream (the problem is a fit's / an extend's temporary): the model takes over the problem's first slot stream instead
+  // of a stream of its own -- one stream fewer per fit in flight (HIP maps streams onto a few hardware queues, and a stream
+  // that shares its queue with another fit's long kernel waits for it: StreamPool)
+  Slot<T>& s0 = prob.slots[di][0];
+  if (adopt_stream && s0.stream && !s0.stream_adopted) {
+    m->stream = s0.stream;
+    m->stream_kind = STREAM_SLOT;
+    s0.stream_adopted = true;
+  } else {
+    m->stream = g_stream_pool.get(m->dev, STREAM_MODEL);
+  }
   m->X = m->palloc(sizeof(T) * (size_t)prob.n * prob.d);
   m->alpha = m->palloc(sizeof(T) * prob.np);
   { bool fr; m->Kinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->Xinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->kinv_bytes = sizeof(T) * nn; }
@@ -1744,8 +1885,11 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   const auto tf0 = std::chrono::steady_clock::now();
   // like_fit: the evaluation path (launches / task queue) is a function of n alone, also for a fit with one slot per device
   // (n_restarts = 0, or no more runs than devices): `extend` at the fitted theta then repeats the fit's own evaluation bit for bit
+  SmallArrival arrival;  // other threads' small fits wait (briefly) for this one's runs before they launch: SmallBatcher
+  if (small_fit) arrival.announce();
   Problem<T> prob(ctx, X, y, n, d, nu, n_slots, false, true);
   const auto tf1 = std::chrono::steady_clock::now();
+  if (!(small_fit && prob.small_)) arrival.arrived();
 
   std::vector<double> lnlo(p), lnhi(p);
   for (int i = 0; i < p; ++i) {
@@ -1768,7 +1912,20 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
     };
     const int cap = opt.trace_cap > 0 ? opt.maxeval : 0;  // per run; the merged trace is cut at opt.trace_cap below
     std::vector<RunWs> ws(nruns);
-    auto free_all = [&]() {};  // the trace arrays belong to the problem's pooled allocations (released with it)
+    // per run, in pinned memory: the result and the word the kernel sets when the run is over (SmallFit::hres / hdone)
+    struct alignas(64) HostRun {
+      SmallFitResult res;
+      unsigned long long done;
+    };
+    const size_t hruns_bytes = (sizeof(HostRun) * (size_t)nruns + 4095) / 4096 * 4096;
+    HostRun* hruns = static_cast<HostRun*>(g_host_pool.get(hruns_bytes));
+    std::vector<std::shared_ptr<SmallBatch>> batches(ndev);
+    bool runs_over = false;
+    auto free_all = [&]() {  // (the trace arrays belong to the problem's pooled allocations, released with it)
+      for (auto& b : batches) small_batch_leave(b, runs_over);
+      batches.clear();
+      g_host_pool.put(hruns, hruns_bytes);
+    };
     try {
       std::vector<int> next_slot(ndev, 0);
       // the runs of a device are the workgroups of ONE launch on the device's first slot stream (one stream per fit and device:
@@ -1809,27 +1966,51 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         f.maxeval = opt.maxeval; f.memory = opt.lbfgs_memory > 0 ? opt.lbfgs_memory : lo_opt.memory; f.fixed_work = opt.fixed_work != 0;
         f.pgtol = lo_opt.pgtol; f.ftol = lo_opt.ftol;
         f.res = w.res; f.trace_theta = w.tr_theta; f.trace_lml = w.tr_lml; f.trace_grad = w.tr_grad; f.trace_cap = cap;
+        hruns[r].done = 0;
+        f.hres = &hruns[r].res; f.hdone = &hruns[r].done;
         fits_on[w.di].push_back(f);
       }
       for (int di = 0; di < ndev; ++di) {
         if (fits_on[di].empty()) continue;
         HIPCHECK(hipSetDevice(ctx->devs[di]));
-        hipStream_t st = prob.slots[di][0].stream;
-        SmallFit* fs_dev = prob.template palloc<SmallFit>(ctx->devs[di], fits_on[di].size());
-        HIPCHECK(hipMemcpyAsync(fs_dev, fits_on[di].data(), sizeof(SmallFit) * fits_on[di].size(), hipMemcpyHostToDevice, st));  // fits_on lives until the runs are collected
-        launch_small_fit<T>(fs_dev, (int)fits_on[di].size(), prob.nu2, st);
-        CHECK_LAUNCHES();
+        // the grid runs on the batch's stream: what this fit queued on its own (features, observations, start points) is there first
+        HIPCHECK(hipStreamSynchronize(prob.slots[di][0].stream));
+        batches[di] = small_batch_submit<T>(ctx->devs[di], prob.nu2, fits_on[di], arrival);
       }
+      // every run's word, in run order.  The stream is asked now and then: a grid that is over without the word (a fault) must not
+      // leave this thread spinning.
+      auto wait_run = [&](int r, int di) {
+        using namespace std::chrono;
+        const volatile unsigned long long* q = &hruns[r].done;
+        auto last_query = steady_clock::now();
+        for (unsigned it = 1;; ++it) {
+          if (*q == 1ull) break;
+          if (it < 256) {
+            __builtin_ia32_pause();
+          } else {
+            std::this_thread::sleep_for(microseconds(40));
+            if (steady_clock::now() - last_query > milliseconds(20)) {
+              last_query = steady_clock::now();
+              const hipError_t e = hipStreamQuery(batches[di]->stream);
+              if (e == hipSuccess) {
+                if (*q == 1ull) break;
+                throw HipError{hipErrorLaunchFailure, "small fit: the launch is over and a run never reported", __LINE__};
+              }
+              if (e != hipErrorNotReady) throw HipError{e, "hipStreamQuery (small-fit launch)", __LINE__};
+            }
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      };
+      for (int r = 0; r < nruns; ++r) wait_run(r, ws[r].di);
+      runs_over = true;
       int total_evals = 0, total_not_pd = 0, trace_n = 0;
       for (int r = 0; r < nruns; ++r) {
         RunWs& w = ws[r];
         HIPCHECK(hipSetDevice(ctx->devs[w.di]));
         Slot<T>& s = prob.slots[w.di][w.si];
         hipStream_t st = prob.slots[w.di][0].stream;
-        HIPCHECK(hipStreamSynchronize(st));
-        SmallFitResult hr;
-        HIPCHECK(hipMemcpyAsync(&hr, w.res, sizeof(hr), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
+        const SmallFitResult hr = hruns[r].res;
         total_evals += hr.n_evals;
         total_not_pd += hr.n_not_pd;
         s.best_idx = hr.best_idx;
@@ -1995,7 +2176,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   if (theta_best) memcpy(theta_best, th.data(), sizeof(double) * p);
   if (lml_best) *lml_best = best.best_lml;
   const auto tf2 = std::chrono::steady_clock::now();
-  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data());
+  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data(), model_adopts_stream());
   if (timing) {
     const auto tf3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2030,7 +2211,7 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
       if (hi[i] < v) v = hi[i];
       th[i] = std::log(v);
     }
-  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml, true);
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml, true, nullptr, model_adopts_stream());
   return HBEGP_OK;
 }
 
@@ -2067,7 +2248,7 @@ static int do_extend_from(hbegp_ctx* ctx, hbegp_model* prior, const T* X, const 
   if (incremental) *incremental = 1;
   (void)p;
   const auto t2 = now();
-  if (model_out) *model_out = make_model<T>(prob, 0, 0, prior->theta.data(), s.hOut->lml, true);
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, prior->theta.data(), s.hOut->lml, true, nullptr, model_adopts_stream());
   const auto t3 = now();
   if (timing) fprintf(stderr, "extend_from: problem %.3f ms, factor %.3f ms, model %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
   return HBEGP_OK;

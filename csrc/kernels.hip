@@ -2603,6 +2603,7 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(const SmallFit* __res
   int best_idx = -1, best_eval = 0, n_evals = 0, n_not_pd = 0;
   double best_lml = -INFINITY;
   double cur_param = 0.0;  // wave 0, lane = parameter: what the evaluation in flight runs with
+  double best_th = 0.0, best_par = 0.0;  // wave 0, lane = parameter: the captured evaluation's (for the pinned copy of the result)
   // wave 0: the requested point -> clamped linear-space parameters (fit.rs:94-96; the noise is not clamped, :96)
   auto publish_request = [&]() {
     if (act) {
@@ -2669,6 +2670,8 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(const SmallFit* __res
         if (act) {
           res->best_theta[lane] = th;
           res->best_params[lane] = cur_param;
+          best_th = th;
+          best_par = cur_param;
         }
       }
       // fit.rs:128-133: the optimiser minimises -lml
@@ -2688,6 +2691,24 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(const SmallFit* __res
     res->best_eval = best_eval;
     res->n_evals = n_evals;
     res->n_not_pd = n_not_pd;
+  }
+  // the run is over: its result to the pinned block and the word its host thread polls (every wave's device writes of the last
+  // evaluation are behind an agent-scope fence and a barrier; a later kernel of any stream starts with an acquire of its own)
+  if (wave == 0 && f.hres) {
+    SmallFitResult* h = f.hres;
+    if (act) {
+      h->best_theta[lane] = best_th;
+      h->best_params[lane] = best_par;
+    }
+    if (lane == 0) {
+      h->best_idx = best_idx;
+      h->best_lml = best_lml;
+      h->best_eval = best_eval;
+      h->n_evals = n_evals;
+      h->n_not_pd = n_not_pd;
+    }
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(f.hdone, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -48,7 +48,9 @@
  *     their own: one evaluation is one launch that keeps K, L, L^-1, K^-1 and alpha in a compute unit's LDS, and one optimiser
  *     run of a fit is one persistent launch (evaluation + bounded L-BFGS step + capture on the device); the host only starts
  *     the runs side by side and collects.  Same entry points, same contracts; HBEGP_SMALL=0 / HBEGP_SMALL_FIT=0 select the
- *     general path / the host-driven optimiser for comparison.
+ *     general path / the host-driven optimiser for comparison.  Such fits issued by several threads at the same time share
+ *     their launches (one grid carries the runs of all fits that arrive within a few milliseconds of each other; a thread
+ *     alone never waits): 16 threads reach ~1,100 fits/s at n = 128 where one reaches 95, each fit bit for bit its solo result.
  */
 #ifndef HBEGP_H
 #define HBEGP_H

@@ -21,7 +21,7 @@ exactly factored rounded K at 0.3 - 4 sigma; the allowance is 8 sigma.
     |gpu32 - truth| <= max(1e-4 * scale, 2 * |lapack32 - truth|, 8 * sigma32)
 
 One case is outside every rule: where the reference's own arithmetic is further from the truth than the LARGEST entry of the
-truth is from zero (|lapack - truth| >= max |truth|: not one correct digit -- f32 at a corner of the box with cond(K) beyond
+truth is from zero (|lapack - truth| >= max(1, max |truth|): not one correct digit -- f32 at a corner of the box with cond(K) beyond
 1 / eps_f32; seen once, K^-1 of a captured f32 model: LAPACK off by 3.6e5 on entries of at most 3.0e4), twice one noise draw
 against another noise draw decides nothing.  Such a comparison is counted (`n_nodigits`, shown in the summary), the engine's
 values must be finite, and nothing else is asserted.
@@ -73,7 +73,7 @@ class Judge:
         s = max(1.0, float(np.max(np.abs(truth))) if scale is None else float(scale))
         e_gpu = float(np.max(np.abs(np.asarray(got, dtype=np.float64) - truth)))
         e_lap = float(np.max(np.abs(np.asarray(lapack, dtype=np.float64) - truth)))
-        if e_lap >= float(np.max(np.abs(truth))) > 0.0:
+        if e_lap >= s:  # (s = max(1, largest entry of the truth): the scale every bar here is relative to)
             self.n_nodigits += 1
             assert np.all(np.isfinite(np.asarray(got, dtype=np.float64))), f"{what}: not finite"
             return

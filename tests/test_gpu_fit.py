@@ -474,3 +474,51 @@ def test_concurrent_fits_on_one_context_reproduce_the_solo_fit(n, dtype):
         assert r[0] == solo[0] and np.array_equal(r[1], solo[1])
         for a, b in zip(r[2:], solo[2:]):
             assert np.array_equal(a, b)
+
+
+def test_small_fits_of_different_shapes_share_launches_and_keep_their_bits():
+    # Fits of up to 128 rows from several host threads are handed to ONE grid (csrc/hbegp.cpp: SmallBatcher): each run is a
+    # workgroup, each host thread polls the pinned words of its own runs.  The company must not matter: six threads with
+    # different data (rows, dimensions, budgets, one of them traced, one converging instead of fixed work) fit three times each,
+    # side by side; every result equals the same fit alone, bit for bit -- model, predictions and the whole trace.
+    import threading
+
+    shapes = [("C1", 40, 20, True), ("M", 64, 30, True), ("C2", 100, 25, True), ("M", 128, 20, True), ("C3", 90, 35, False), ("C1", 64, 15, True)]
+    ctx = gpr.Context(device_ids=[0])
+    jobs = []
+    for i, (cfg, n, maxeval, fixed) in enumerate(shapes):
+        w = synth.make_workload(cfg, n=n)
+        jobs.append((w, synth.restart_points(cfg, w["lo"], w["hi"], 1 + i % 3), maxeval, fixed, i == 2))
+
+    def fit(job):
+        w, starts, maxeval, fixed, trace = job
+        fk = gpr.FittedKernel.new(w["X"], w["y"], w["theta0"], w["lo"], w["hi"], starts, ctx=ctx, maxeval=maxeval, fixed_work=fixed, trace=trace)
+        alpha, kinv = fk.arrays()
+        mean, var, _ = fk.predict(w["X"][:5])
+        out = [np.array([fk.lml, fk.n_evals]), fk.theta.copy(), alpha, kinv, mean, var]
+        if trace:
+            out += [fk.trace["theta"].copy(), fk.trace["lml"].copy(), fk.trace["grad"].copy(), fk.trace["run"].copy()]
+        fk.release()
+        return out
+
+    solo = [fit(j) for j in jobs]
+    results, errors = [[] for _ in jobs], []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                results[i].append(fit(jobs[i]))
+        except Exception as e:  # noqa: BLE001 -- the assertion below reports it
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    ctx.close()
+    assert not errors, errors
+    for i, rs in enumerate(results):
+        assert len(rs) == 3
+        for r in rs:
+            assert len(r) == len(solo[i])
+            for a, b in zip(r, solo[i]):
+                assert np.array_equal(a, b), (i, shapes[i])

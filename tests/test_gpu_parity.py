@@ -410,58 +410,35 @@ def test_fresh_pool_blocks_are_cleared_before_their_first_writer(dtype, monkeypa
     # once; hipMemset on device memory is queued on the NULL stream and returns at once, while the engine's streams are
     # non-blocking ones that do not wait for the null stream -- the clear could land on top of (or concurrently with) the block's
     # first writer.  HBEGP_POOL_FRESH=1 makes every block a fresh one (as in a fresh process), HBEGP_POOL_NULL_DELAY_MB queues a
-    # long fill in front of every clear so that an unsynchronised clear is LATE for certain.  The launch path (n = 589: five
-    # 128-blocks) has no other null-stream synchronisation between the pool and the first launch.
-    #   (a) the shipped clear (hipMemsetAsync + hipStreamSynchronize(nullptr)): oracle results at the plain bar;
-    #   (b) HBEGP_POOL_OLD_CLEAR=1 (round 1-4's hipMemset alone): the model is damaged -- if it were NOT, the diagnosis of
-    #       round 4 would be wrong and that failure still open.
-    n, d = 589, 5
-    w = synth.make_workload("C2", n=n)
-    rng = np.random.default_rng(589)
-    X = rng.random((n, d)).astype(dtype)
-    y = w["y"][:n].astype(dtype)
-    theta = np.concatenate([[math.log(0.05), 0.0], np.log(np.full(d, 0.6))])
-    s2, c, ell = split_theta(theta)
-    Xs = rng.random((5, d)).astype(dtype)
-    ref = O.extend(X.astype(np.float64), y.astype(np.float64), s2, c, ell, 2.5)
-    rm, rv, _ = O.predict(Xs.astype(np.float64), X.astype(np.float64), ref["alpha"], ref["k_inv"], c, ell, 2.5)
+    # long fill in front of every clear so that an unsynchronised clear is LATE for certain (tests/pool_clear_scenario.py).
+    #   (a) the shipped clear (a stream of the pool's own, waited for): oracle results at the plain bar, in this process;
+    #   (b) HBEGP_POOL_OLD_CLEAR=1 (round 1-4's hipMemset alone), in a FRESH process: the model is damaged -- if it were NOT, the
+    #       diagnosis of round 4 would be wrong and that failure still open.  A fresh process because the damage needs the
+    #       model's stream on another hardware queue than the null stream's (on the same queue it runs behind the clear and is
+    #       safe by accident); HIP deals queues in stream-creation order, which only a fresh process fixes.  Inside the suite's
+    #       process this leg failed to damage in about one run of six, and under eager launches always.
+    import json
+    import subprocess
+    import sys
+
+    import pool_clear_scenario as S
+
     tol = F64_TOL if dtype == np.float64 else F32_TOL
     monkeypatch.setenv("HBEGP_POOL_FRESH", "1")
     monkeypatch.setenv("HBEGP_POOL_NULL_DELAY_MB", "8192")
-
-    def run():
-        import time
-
-        fk = gpr.FittedKernel.extend(X, y, theta)
-        try:
-            # an unsynchronised clear is queued behind ~3 ms of null-stream fill per work matrix (six of them): by now it has
-            # landed on top of the model's arrays, which were filled the moment they were handed out
-            time.sleep(0.3)
-            mean, var, _ = fk.predict(Xs)
-            alpha, _ = fk.arrays()
-        finally:
-            fk.release()
-        return (float(np.max(np.abs(mean - rm))) / max(1.0, np.abs(rm).max()), float(np.max(np.abs(var - np.maximum(rv, 0)))) / c,
-                float(np.max(np.abs(alpha - ref["alpha"]))) / max(1.0, np.abs(ref["alpha"]).max()))
-
+    run = S.scenario(dtype)
     devs = run()
     assert max(devs) <= tol, devs
-    monkeypatch.setenv("HBEGP_POOL_OLD_CLEAR", "1")
-    old = None
-    try:
-        old = run()
-        damaged = not (max(old) <= tol)  # NaN counts as damaged
-    except gpr.HbegpError as e:
-        damaged = True  # e.g. "not positive definite": the kernel matrix was zeroed under the factorisation
-        old = f"error: {e}"
-    finally:
-        # drain the null stream (late clears may still be queued) before any other test recycles these blocks: every fresh block
-        # of the shipped path waits for the null stream
-        monkeypatch.delenv("HBEGP_POOL_OLD_CLEAR")
-        again = run()
-    print(f"old clear ({np.dtype(dtype).name}): {old}; shipped clear: {devs}, again {again}")
-    # (eager launches, HBEGP_NO_GRAPH=1 in tools/gpu_matrix.sh: the old clear does no damage there -- deviations 5e-14 -- so the
-    # demonstration leg is asserted for the shipped configuration only)
-    if os.environ.get("HBEGP_NO_GRAPH", "0") in ("", "0"):
-        assert damaged, f"the unsynchronised clear did not damage the model (deviations {old}): round 4's diagnosis does not hold"
+    env = dict(os.environ, HBEGP_POOL_OLD_CLEAR="1")
+    for k in ("HBEGP_NO_GRAPH", "GPU_MAX_HW_QUEUES"):  # (tools/gpu_matrix.sh: the demonstration is about the shipped configuration)
+        env.pop(k, None)
+    cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pool_clear_scenario.py"), np.dtype(dtype).name],
+                        env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert lines, (cp.stdout[-500:], cp.stderr[-500:])
+    old = json.loads(lines[-1])
+    damaged = "error" in old or not (max(old["deviations"]) <= tol)  # NaN counts as damaged
+    again = run()
+    print(f"old clear ({np.dtype(dtype).name}, fresh process): {old}; shipped clear: {devs}, again {again}")
+    assert damaged, f"the unsynchronised clear did not damage the model ({old}): round 4's diagnosis does not hold"
     assert max(again) <= tol, again

@@ -23,18 +23,26 @@ starts = synth.restart_points("M", w["lo"], w["hi"], 2)
 ctx = gpr.Context(device_ids=[0])
 
 
+phases = np.zeros(3)  # FIT_PHASES=1: seconds in new / predict / release, summed over all threads (racy adds: a diagnostic)
+
+
 def fit():
+    t0 = time.perf_counter()
     fk = gpr.FittedKernel.new(X, y, w["theta0"], w["lo"], w["hi"], starts, nu=2.5, ctx=ctx, maxeval=150, fixed_work=True)
+    t1 = time.perf_counter()
     mean, var, _ = fk.predict(X[:8])  # (the whole K^-1 is a 134 MB copy at n = 4096: the predictions stand in for the model's bits)
+    t2 = time.perf_counter()
     out = (fk.lml, fk.theta.copy(), np.concatenate([mean, var]))
     fk.release()
+    t3 = time.perf_counter()
+    phases[:] += (t1 - t0, t2 - t1, t3 - t2)
     return out
 
 
 solo = fit()
 summary = {"n": n, "dtype": np.dtype(dtype).name, "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"), "fits_per_s": {}, "bitwise_equal_to_solo": True}
 for k in ks:
-    reps = max(2, 24 // k) if n <= 256 else max(2, 8 // k)
+    reps = max(8, 24 // k) if n <= 256 else max(2, 8 // k)  # (small fits: rounds of several threads need a few rounds to fall into step)
     results = [[] for _ in range(k)]
 
     def work(i):
@@ -46,11 +54,14 @@ for k in ks:
         [t.start() for t in ts]
         [t.join() for t in ts]
     results = [[] for _ in range(k)]
+    phases[:] = 0
     t0 = time.perf_counter()
     ts = [threading.Thread(target=work, args=(i,)) for i in range(k)]
     [t.start() for t in ts]
     [t.join() for t in ts]
     dt = time.perf_counter() - t0
+    if os.environ.get("FIT_PHASES"):
+        print(f"  per fit: new {phases[0] / (k * reps) * 1e3:.2f} ms, predict {phases[1] / (k * reps) * 1e3:.2f} ms, release {phases[2] / (k * reps) * 1e3:.2f} ms")
     same = all(r[0] == solo[0] and np.array_equal(r[1], solo[1]) and np.array_equal(r[2], solo[2]) for rs in results for r in rs)
     print(f"n={n} {np.dtype(dtype).name} k={k}: {k * reps / dt:.2f} fits/s aggregate ({dt / reps * 1e3:.1f} ms per round of {k}); "
           f"every fit bit for bit the solo fit: {same}", flush=True)
