@@ -13,11 +13,24 @@ using namespace hbegp;
 
 template <typename T, int TA, int TB, int PIPE>
 __global__ void __launch_bounds__(512, 2) tile_bench_kernel(T* W1, T* W2, T* W3, int ld, int depth, int reps, int flags,
-                                                            long long* cyc) {
+                                                            long long* cyc, int map) {
   extern __shared__ __align__(16) char smem_raw[];
   const int per_row = ld / TB;
   const int tile = blockIdx.x;
-  const int row0 = (tile / per_row) * TA % ld, col0 = (tile % per_row) * TB;
+  int row0 = (tile / per_row) * TA % ld, col0 = (tile % per_row) * TB;
+  // TILE_UBENCH_MAP (timing rounds only; workgroup t runs on XCD t % 8).  0: tiles in row-major order -- the 8 tiles of one column
+  // of tiles sit on ONE XCD (they share their B panel in its L2), the tiles of a row 4 per XCD.  1: no two workgroups of an XCD
+  // share an operand panel (A from W2, B from W3; the eight workgroups t = 8q .. 8q+7 share theirs, one per XCD).  2: all
+  // workgroups of an XCD run the SAME tile (everything but the first touch comes from the L2).
+  if (map == 1) {
+    const int q = (tile / 8) % (ld / TA);
+    row0 = q * TA;
+    col0 = ((q * 5 + 3) % (ld / TB)) * TB;
+    flags = DAGF_ABUF | DAGF_B3;
+  } else if (map == 2) {
+    row0 = (tile % 8) * TA;
+    col0 = ((tile % 8) * 3 % (ld / TB)) * TB;
+  }
   auto nop = []() {};
   const long long t0 = (long long)__builtin_readcyclecounter();
   for (int r = 0; r < reps; ++r) {
@@ -29,6 +42,7 @@ __global__ void __launch_bounds__(512, 2) tile_bench_kernel(T* W1, T* W2, T* W3,
   if (threadIdx.x == 0) cyc[blockIdx.x] = (long long)__builtin_readcyclecounter() - t0;
 }
 
+static int g_map = 0;
 template <typename T, int TA, int TB, int PIPE>
 static float run(T* W1, T* W2, T* W3, int ld, int depth, int reps, int flags, int nwg, long long* cyc) {
   static bool once = false;
@@ -41,7 +55,7 @@ static float run(T* W1, T* W2, T* W3, int ld, int depth, int reps, int flags, in
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(fn, dim3(nwg), dim3(512), DAG_LDS_BYTES, 0, W1, W2, W3, ld, depth, reps, flags, cyc);
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(512), DAG_LDS_BYTES, 0, W1, W2, W3, ld, depth, reps, flags, cyc, g_map);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -111,6 +125,8 @@ int main(int argc, char** argv) {
     }
   }
   // timing: interleaved rounds
+  g_map = getenv("TILE_UBENCH_MAP") ? atoi(getenv("TILE_UBENCH_MAP")) : 0;
+  printf("timing with TILE_UBENCH_MAP=%d\n", g_map);
   std::vector<std::vector<float>> ms(vs.size());
   std::vector<std::vector<double>> kc(vs.size());
   std::vector<long long> hc(4096);
