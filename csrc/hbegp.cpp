@@ -549,7 +549,6 @@ template <typename T>
 struct Slot {
   int dev = 0;
   hipStream_t stream = nullptr;
-  bool stream_adopted = false;  // a model built from this (temporary) problem keeps the stream: it goes back to the pool with the model
   T *W1 = nullptr, *W2 = nullptr, *Kinv[2] = {nullptr, nullptr}, *alpha[2] = {nullptr, nullptr};
   T* W3 = nullptr;  // f32 problems only: the Cholesky factor L (lower), kept for the refinement of the panel solves
   T *ldiag = nullptr, *wbuf = nullptr;
@@ -950,7 +949,7 @@ struct Problem : ProblemBase {
         for (int b = 0; b < 2; ++b) g_pool.put(s.dev, s.Kinv[b], nnb);
         g_pool.put(s.dev, s.small_slab, s.small_slab_bytes);
         g_host_pool.put(s.host_slab, s.host_slab_bytes);
-        if (!s.stream_adopted) g_stream_pool.put(s.dev, s.stream);  // synchronised above
+        g_stream_pool.put(s.dev, s.stream);  // synchronised above
       }
     }
     for (const Pooled& q : pooled_) g_pool.put(q.dev, q.p, q.bytes);  // features, targets, task queues, control words, schedule tables
@@ -1651,7 +1650,6 @@ struct hbegp_model {
   EvalParams* dP = nullptr;
   EvalOut* dOut = nullptr;
   hipStream_t stream = nullptr;
-  int stream_kind = 1;  // StreamPool list the stream goes back to (STREAM_MODEL; STREAM_SLOT when adopted from the fit's problem)
   // predict scratch (grow-only)
   int cap_m = 0;
   void *Xs = nullptr, *Ks = nullptr, *Q = nullptr, *mean = nullptr, *var = nullptr;
@@ -1686,34 +1684,23 @@ struct hbegp_model {
     g_pool.put(dev, Kinv, kinv_bytes); g_pool.put(dev, Xinv, kinv_bytes);
     for (const Pooled& q : pooled) g_pool.put(dev, q.p, q.bytes);
     g_host_pool.put(sm_hin, sm_hin_bytes); g_host_pool.put(sm_hout, sm_hout_bytes);
-    g_stream_pool.put(dev, stream, stream_kind);  // synchronised above
+    g_stream_pool.put(dev, stream, STREAM_MODEL);  // synchronised above
   }
 };
 
-static bool model_adopts_stream() {
-  static const bool on = env_int("HBEGP_MODEL_OWN_STREAM", 0) == 0;
-  return on;
-}
 template <typename T>
 static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double* theta_clamped, double lml,
-                               bool w2_current = false, const double* params_linear = nullptr, bool adopt_stream = false) {
+                               bool w2_current = false, const double* params_linear = nullptr) {
   Slot<T>& s = prob.slots[di][si];
   HIPCHECK(hipSetDevice(s.dev));
   std::unique_ptr<hbegp_model> m(new hbegp_model());
   m->dev = s.dev; m->n = prob.n; m->d = prob.d; m->np = prob.np; m->nu2 = prob.nu2; m->is_f32 = prob.is_f32; m->lml = lml;
   m->theta.assign(theta_clamped, theta_clamped + prob.d + 2);
   const size_t nn = (size_t)prob.np * prob.np;
-  // adopt_stream (the problem is a fit's / an extend's temporary): the model takes over the problem's first slot stream instead
-  // of a stream of its own -- one stream fewer per fit in flight (HIP maps streams onto a few hardware queues, and a stream
-  // that shares its queue with another fit's long kernel waits for it: StreamPool)
-  Slot<T>& s0 = prob.slots[di][0];
-  if (adopt_stream && s0.stream && !s0.stream_adopted) {
-    m->stream = s0.stream;
-    m->stream_kind = STREAM_SLOT;
-    s0.stream_adopted = true;
-  } else {
-    m->stream = g_stream_pool.get(m->dev, STREAM_MODEL);
-  }
+  // (a model that took over its fit's first slot stream instead -- one stream fewer per fit in flight -- was tried in round 5:
+  // nothing gained for fits side by side, and the slot streams then change hands from fit to fit, so that two slots of one fit
+  // end up on one hardware queue now and then: bench 1.777 -> 1.739, solo fits at n = 1024 16.4 -> 6.7 per s in some processes)
+  m->stream = g_stream_pool.get(m->dev, STREAM_MODEL);
   m->X = m->palloc(sizeof(T) * (size_t)prob.n * prob.d);
   m->alpha = m->palloc(sizeof(T) * prob.np);
   { bool fr; m->Kinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->Xinv = g_pool.get(m->dev, sizeof(T) * nn, &fr); m->kinv_bytes = sizeof(T) * nn; }
@@ -2177,7 +2164,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   if (theta_best) memcpy(theta_best, th.data(), sizeof(double) * p);
   if (lml_best) *lml_best = best.best_lml;
   const auto tf2 = std::chrono::steady_clock::now();
-  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data(), model_adopts_stream());
+  if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data());
   if (timing) {
     const auto tf3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2212,7 +2199,7 @@ static int do_extend(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, doubl
       if (hi[i] < v) v = hi[i];
       th[i] = std::log(v);
     }
-  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml, true, nullptr, model_adopts_stream());
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, th.data(), lml, true);
   return HBEGP_OK;
 }
 
@@ -2249,7 +2236,7 @@ static int do_extend_from(hbegp_ctx* ctx, hbegp_model* prior, const T* X, const 
   if (incremental) *incremental = 1;
   (void)p;
   const auto t2 = now();
-  if (model_out) *model_out = make_model<T>(prob, 0, 0, prior->theta.data(), s.hOut->lml, true, nullptr, model_adopts_stream());
+  if (model_out) *model_out = make_model<T>(prob, 0, 0, prior->theta.data(), s.hOut->lml, true);
   const auto t3 = now();
   if (timing) fprintf(stderr, "extend_from: problem %.3f ms, factor %.3f ms, model %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
   return HBEGP_OK;
