@@ -292,7 +292,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // for all of it (measured: 16 threads, 16 hardware queues: 560 fits/s where 16 / 10.5 ms = 1,500 would fit the chip; more
 // queues made it worse).  So: a thread that arrives with its runs joins the batch that is open for its (device, kernel) or opens
 // one; whoever opened it waits until no other thread is on its way (threads announce themselves when they enter the small-fit
-// path: SmallBatcher::arriving), at most 3 ms of a ~10 ms fit (HBEGP_SMALL_BATCH_US; measured at 16 threads: 0.3 ms 724, 1 ms 959, 3 ms
+// path: SmallBatcher::arriving) and none has just come back from a small fit (g_small_recent below), at most 3 ms of a ~10 ms fit (HBEGP_SMALL_BATCH_US; measured at 16 threads: 0.3 ms 724, 1 ms 959, 3 ms
 // 1,113 fits/s -- under load a thread needs 2-3 ms to set its problem up), and launches all runs in ONE grid; every thread then polls the pinned words of its
 // OWN runs (SmallFit::hdone) -- it neither waits for the other fits of the launch nor synchronises a stream.  One thread alone
 // launches at once.  The workgroups of a launch do not depend on each other, so a run's bits do not depend on its company.
@@ -313,9 +313,39 @@ struct SmallBatcher {
   std::atomic<int> arriving{0};  // threads inside the small-fit path that have not handed in their runs yet
 };
 static SmallBatcher g_small_batcher;
-struct SmallArrival {  // RAII: "I am on my way with runs"
-  bool counted = false;
-  void announce() { if (!counted) { g_small_batcher.arriving.fetch_add(1); counted = true; } }
+// Threads that have just come back from a small fit are the ones most likely to bring the next one: each thread keeps the time of
+// its last return in a slot of this table (0 while it is inside a fit), and the thread that opens a batch also waits for those
+// whose return is younger than HBEGP_SMALL_BATCH_RECENT_US (4 ms) -- without this, threads that finish together drift apart
+// again (whoever is back first sees nobody on the way and launches alone: measured, 16 threads, 68 of 101 grids carried one fit).
+constexpr int SMALL_RECENT_SLOTS = 64;
+static std::atomic<long long> g_small_recent[SMALL_RECENT_SLOTS];
+static std::atomic<int> g_small_recent_next{0};
+static int small_recent_slot() {
+  static thread_local int slot = -1;
+  if (slot < 0) slot = g_small_recent_next.fetch_add(1) % SMALL_RECENT_SLOTS;
+  return slot;
+}
+static long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int small_recent_others(long long window_ns) {
+  const long long now = steady_ns();
+  const int mine = small_recent_slot();
+  int c = 0;
+  for (int i = 0; i < SMALL_RECENT_SLOTS; ++i) {
+    const long long ts = g_small_recent[i].load(std::memory_order_relaxed);
+    if (i != mine && ts != 0 && now - ts < window_ns) ++c;
+  }
+  return c;
+}
+struct SmallArrival {  // RAII: "I am on my way with runs"; on destruction: "I am back" (the time of the return is left in the table)
+  bool counted = false, entered = false;
+  void announce() {
+    if (!counted) {
+      g_small_batcher.arriving.fetch_add(1);
+      counted = true;
+      entered = true;
+      g_small_recent[small_recent_slot()].store(0, std::memory_order_relaxed);
+    }
+  }
   void arrived() {
     if (counted) {
       g_small_batcher.arriving.fetch_sub(1);
@@ -323,7 +353,10 @@ struct SmallArrival {  // RAII: "I am on my way with runs"
       g_small_batcher.cv.notify_all();
     }
   }
-  ~SmallArrival() { arrived(); }
+  ~SmallArrival() {
+    arrived();
+    if (entered) g_small_recent[small_recent_slot()].store(steady_ns(), std::memory_order_relaxed);
+  }
 };
 static void small_batch_unref_locked(SmallBatch& b);
 // Hands in `mine` (runs of one fit on device `dev`); returns the batch once its grid has been launched.  The caller polls its runs'
@@ -345,8 +378,18 @@ static std::shared_ptr<SmallBatch> small_batch_submit(int dev, int nu2, const st
   ++b->refs;
   arrival.arrived();  // (notifies: a leader waiting for the stragglers looks again)
   if (leader) {
-    if (window_us > 0)
-      B.cv.wait_for(lk, std::chrono::microseconds(window_us), [&] { return B.arriving.load() == 0; });
+    const auto t_open = std::chrono::steady_clock::now();
+    static const long long recent_ns = 1000ll * env_int("HBEGP_SMALL_BATCH_RECENT_US", 4000);
+    if (window_us > 0) {
+      // until nobody is on the way and nobody has just come back (their marks expire by themselves: look again every 200 us)
+      const auto deadline = t_open + std::chrono::microseconds(window_us);
+      while (std::chrono::steady_clock::now() < deadline && (B.arriving.load() != 0 || small_recent_others(recent_ns) != 0))
+        B.cv.wait_for(lk, std::chrono::microseconds(200));
+    }
+    static const bool log_batches = env_int("HBEGP_SMALL_BATCH_LOG", 0) != 0;
+    if (log_batches)
+      fprintf(stderr, "small-fit batch: %zu runs, waited %.0f us for stragglers (%d still on their way, %d just back)\n", b->fits.size(),
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_open).count(), B.arriving.load(), small_recent_others(recent_ns));
     b->closed = true;
     B.open.erase(key);
     lk.unlock();

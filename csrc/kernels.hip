@@ -1379,7 +1379,16 @@ __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv,
     double ya = 0, ld = 0;
     if (threadIdx.x < COLS && j < np) {
       double a = 0;
-      for (int c = j / 256; c < fin.nchunks; ++c) a += part[(size_t)c * np + j];
+      // chunk by chunk in ascending order; the loads of eight chunks are issued together (one at a time: 16 dependent round trips at n = 4096)
+      int c = j / 256;
+      for (; c + 8 <= fin.nchunks; c += 8) {
+        double pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = part[(size_t)(c + u) * np + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += pv[u];
+      }
+      for (; c < fin.nchunks; ++c) a += part[(size_t)c * np + j];
       const T at = (T)a;
       fin.alpha[j] = (j < fin.n) ? at : T(0);
       if (j < fin.n) {
