@@ -131,7 +131,6 @@ struct DagTask {
 };
 static_assert(DAG_MAXSIG == 3, "DagTask::sig has three entries: dword 5 high half, dword 6 low half, dword 6 high half");
 static_assert(sizeof(DagTask) == 48, "DagTask layout");  // dag_kernel decodes it dword by dword: keep the field order
-constexpr int ALPHA_TICKET_OFF = 8;  // launch_alpha_lml: first int of the fused reduction's tickets behind Slot::tickets
 constexpr int DAG_CTRL_WORDS = 4;     // ctrl[0] queue head, [1] first task that gave up waiting (+1), [2..3] spare; counters follow
 constexpr int DAG_INFO_TIMEOUT = -2;  // written to EvalOut::info when a wait exceeded its bound (a bug, never a data property)
 struct DagLaunch {
@@ -168,9 +167,7 @@ void launch_leaf(T* W1, T* W2, int ld, int blk, T* ldiag, int* info, hipStream_t
 
 // alpha = X^T (X y), lml pieces.  X lower-triangular np x np in W2.  part: [np/256][np] scratch.
 template <typename T>
-// ticket (device ints, zero between launches): the last workgroup of the reduction forms the lml itself (no lml_final launch).
-// Round 5: with a ticket the reductions run inside the X^T w launch (no alpha_reduce launch either); that form uses the ints
-// [ALPHA_TICKET_OFF, ALPHA_TICKET_OFF + 1 + np / 64) behind `ticket` and 2 np / 64 doubles behind the chunk partials in `part`.
+// ticket (device int, zero between launches): the last workgroup of the reduction forms the lml itself (no lml_final launch).
 void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, T* wbuf, double* part, T* alpha,
                       EvalOut* out, const int* info, hipStream_t s, int* ticket = nullptr);
 

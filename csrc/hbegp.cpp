@@ -766,11 +766,10 @@ struct Problem : ProblemBase {
         {
           auto up = [](size_t v) { return (v + 255) / 256 * 256; };
           const size_t b_vec = up(sizeof(T) * np);
-          const size_t b_part_t = up(sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)(np / 64 + 4) + 64));  // chunk partials, then the reduction's per-wave sums
+          const size_t b_part_t = up(sizeof(double) * ((size_t)((np + 255) / 256) * np + 2 * (size_t)((np + 255) / 256) + 64));
           const size_t b_part_g = up(sizeof(double) * gradtrace_part_elems(np, d));
           const size_t b_p = up(sizeof(EvalParams)), b_o = up(sizeof(EvalOut));
-          const size_t b_tickets = up(sizeof(int) * (size_t)(ALPHA_TICKET_OFF + 1 + np / 64 + 8));  // [0] alpha / lml, [1] gradient, [ALPHA_TICKET_OFF ..] the fused alpha reduction
-          s.small_slab_bytes = 4 * b_vec + b_part_t + b_part_g + b_p + b_o + b_tickets;
+          s.small_slab_bytes = 4 * b_vec + b_part_t + b_part_g + b_p + b_o + 256;
           bool fs = false;
           s.small_slab = g_pool.get(s.dev, s.small_slab_bytes, &fs);
           char* q = static_cast<char*>(s.small_slab);
@@ -784,7 +783,7 @@ struct Problem : ProblemBase {
           s.dOut = reinterpret_cast<EvalOut*>(q); q += b_o;
           s.tickets = reinterpret_cast<int*>(q);
           HIPCHECK(hipMemsetAsync(s.dOut, 0, sizeof(EvalOut), st0));
-          HIPCHECK(hipMemsetAsync(s.tickets, 0, b_tickets, st0));
+          HIPCHECK(hipMemsetAsync(s.tickets, 0, 256, st0));
           const size_t h_p = up(sizeof(EvalParams));
           s.host_slab_bytes = h_p + up(sizeof(EvalOut));
           s.host_slab = g_host_pool.get(s.host_slab_bytes);

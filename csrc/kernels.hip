@@ -1242,13 +1242,12 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // and the stale lines of its L2) and then sees everybody's words.  The ticket word is left at zero for the next launch.
 // Returns true (uniformly) in the last workgroup.
 __device__ __forceinline__ void publish_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// (expected: how many workgroups draw from this ticket word; a second call in one kernel needs a barrier after the first)
-__device__ __forceinline__ bool last_of(int* ticket, int expected) {
+__device__ __forceinline__ bool last_workgroup(int* ticket) {
   __shared__ int s_last;
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = tk == expected - 1;
+    s_last = tk == (int)gridDim.x * (int)gridDim.y - 1;
     if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
@@ -1256,7 +1255,6 @@ __device__ __forceinline__ bool last_of(int* ticket, int expected) {
   if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return last;
 }
-__device__ __forceinline__ bool last_workgroup(int* ticket) { return last_of(ticket, (int)gridDim.x * (int)gridDim.y); }
 
 // w = X y (X lower triangular, row-major): w_i = sum_{k<=i} X[i][k] y[k]   (first half of alpha = X^T (X y), lml.rs:54)
 // Round 5: one wave takes TWO rows, i and np-1-i (together np+1 entries: every wave the same work -- with one wave per row the
@@ -1304,25 +1302,9 @@ __global__ void __launch_bounds__(256) trmv_n_kernel(const T* __restrict__ Xinv,
 // partial[chunk][j] = sum_{i in chunk, i>=j} X[i][j] w[i]; chunk = 256 rows.  Round 5: a thread owns VEC adjacent columns
 // (16-byte loads: 64 lanes cover 128 columns in f64, 256 in f32), wave q of the four takes the rows i = q (mod 4); eight loads in
 // flight per lane.  Fixed order: per column the rows of a wave in ascending order, then the four waves' sums in order.
-// fin.tickets != null (round 5): the launch also forms alpha and the lml -- what alpha_reduce_kernel did in a launch of its own.
-// The workgroups of one column group (the chunks below its diagonal) store their partial sums write-through and draw from the
-// group's ticket; the last one adds the partials of its columns chunk by chunk in ascending order (alpha_reduce_kernel's order),
-// writes alpha and hands over, per wave of 64 columns, the sums of y alpha and log L_jj; the last column group to finish adds
-// those in the order alpha_reduce_kernel's workgroups of 256 columns had -- ((w0 + w1) + w2) + w3 per 256 columns, then the
-// groups in ascending order: the lml keeps its bits.
-template <typename T>
-struct AlphaFinish {
-  int n = 0, nchunks = 0;
-  const T* y = nullptr;
-  const T* ldiag = nullptr;
-  T* alpha = nullptr;
-  double* wsums = nullptr;  // [np / 64][2]
-  EvalOut* out = nullptr;
-  int* tickets = nullptr;   // [0] the launch, [1 + column group]; zero between launches
-};
 template <typename T>
 __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv, int np, const T* __restrict__ w,
-                                                     double* __restrict__ part, const int* info, AlphaFinish<T> fin) {
+                                                     double* __restrict__ part, const int* info) {
   if (*info != 0) return;
   using C = Cfg<T>;
   using vec_t = typename C::vec_t;
@@ -1365,66 +1347,7 @@ __global__ void __launch_bounds__(256) trmv_t_kernel(const T* __restrict__ Xinv,
   for (int e = 0; e < VEC; ++e) red[sgrp][lane * VEC + e] = acc[e];
   __syncthreads();
   for (int c = threadIdx.x; c < COLS; c += 256)
-    if (col0 + c < np) {
-      const double v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-      if (fin.tickets) publish_f64(&part[(size_t)chunk * np + col0 + c], v);
-      else part[(size_t)chunk * np + col0 + c] = v;
-    }
-  if (!fin.tickets) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its partial sums have left the CU
-  __syncthreads();
-  if (!last_of(fin.tickets + 1 + blockIdx.x, fin.nchunks - col0 / 256)) return;  // (chunks above the diagonal returned at once)
-  {
-    const int j = col0 + threadIdx.x;
-    double ya = 0, ld = 0;
-    if (threadIdx.x < COLS && j < np) {
-      double a = 0;
-      // chunk by chunk in ascending order; the loads of eight chunks are issued together (one at a time: 16 dependent round trips at n = 4096)
-      int c = j / 256;
-      for (; c + 8 <= fin.nchunks; c += 8) {
-        double pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = part[(size_t)(c + u) * np + j];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a += pv[u];
-      }
-      for (; c < fin.nchunks; ++c) a += part[(size_t)c * np + j];
-      const T at = (T)a;
-      fin.alpha[j] = (j < fin.n) ? at : T(0);
-      if (j < fin.n) {
-        ya = (double)fin.y[j] * (double)at;
-        ld = log((double)fin.ldiag[j]);
-      }
-    }
-    const double s1 = wave_sum(ya), s2 = wave_sum(ld);
-    if (lane == 0 && sgrp * 64 < COLS && col0 + sgrp * 64 < np) {
-      const int gw = col0 / 64 + sgrp;
-      publish_f64(&fin.wsums[2 * gw], s1);
-      publish_f64(&fin.wsums[2 * gw + 1], s2);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (last_of(fin.tickets, (int)gridDim.x) && threadIdx.x == 0) {
-    const int nw = np / 64;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; 4 * b < nw; ++b) {
-      double b1 = 0, b2 = 0;  // alpha_reduce_kernel's block_sum: red[0] + red[1] + red[2] + red[3], absent waves are zeros
-      for (int q = 0; q < 4; ++q) {
-        const int gw = 4 * b + q;
-        const double v1 = gw < nw ? fin.wsums[2 * gw] : 0.0, v2 = gw < nw ? fin.wsums[2 * gw + 1] : 0.0;
-        b1 = q == 0 ? v1 : b1 + v1;
-        b2 = q == 0 ? v2 : b2 + v2;
-      }
-      s1 += b1;
-      s2 += b2;
-    }
-    EvalOut* out = fin.out;
-    out->yalpha = s1;
-    out->logdet = s2;
-    out->lml = __builtin_fma(-0.5, s1, -s2) - (double)fin.n / 2.0 * log(2.0 * 3.14159265358979323846);
-    atomicOr(&out->done, 1);
-  }
+    if (col0 + c < np) part[(size_t)chunk * np + col0 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
 // lml = -1/2 y^T alpha - sum log L_ii - n/2 log(2 pi)   (lml.rs:57-59); fixed summation order; one thread
@@ -1492,17 +1415,9 @@ void launch_alpha_lml(const T* Xinv, int np, int n, const T* y, const T* ldiag, 
   hipLaunchKernelGGL((trmv_n_kernel<T>), dim3((np / 2 + 3) / 4), dim3(256), 0, s, Xinv, np, n, y, wbuf, info);
   const int nchunks = np / 256 > 0 ? (np + 255) / 256 : 1;
   constexpr int TCOLS = 64 * Cfg<T>::VEC;
-  // the per-workgroup / per-wave sums live behind the chunk partials (part has room for nchunks*np + 2*np/64 doubles)
+  hipLaunchKernelGGL((trmv_t_kernel<T>), dim3((np + TCOLS - 1) / TCOLS, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info);
+  // the per-workgroup sums live behind the chunk partials (part has room for nchunks*np + 2*np/256 doubles)
   double* sums = part + (size_t)nchunks * np;
-  static const bool fuse_alpha = getenv("HBEGP_FUSE_ALPHA") == nullptr || atoi(getenv("HBEGP_FUSE_ALPHA")) != 0;
-  if (ticket && fuse_alpha) {  // two launches: w = X y, then alpha = X^T w with the reductions in its last workgroups
-    AlphaFinish<T> fin;
-    fin.n = n; fin.nchunks = nchunks; fin.y = y; fin.ldiag = ldiag; fin.alpha = alpha; fin.wsums = sums; fin.out = out;
-    fin.tickets = ticket + ALPHA_TICKET_OFF;
-    hipLaunchKernelGGL((trmv_t_kernel<T>), dim3((np + TCOLS - 1) / TCOLS, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info, fin);
-    return;
-  }
-  hipLaunchKernelGGL((trmv_t_kernel<T>), dim3((np + TCOLS - 1) / TCOLS, nchunks), dim3(256), 0, s, Xinv, np, wbuf, part, info, AlphaFinish<T>{});
   const int nblocks = (np + 255) / 256;
   hipLaunchKernelGGL((alpha_reduce_kernel<T>), dim3(nblocks), dim3(256), 0, s, part, nchunks, np, n, y, ldiag, alpha, sums, info,
                      ticket ? out : nullptr, ticket);
