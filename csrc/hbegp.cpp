@@ -313,6 +313,8 @@ struct SmallBatcher {
   std::atomic<int> arriving{0};  // threads inside the small-fit path that have not handed in their runs yet
 };
 static SmallBatcher g_small_batcher;
+static std::mutex g_small_host_mu;      // turn-taking of the host-side phases of small fits (do_fit)
+static std::atomic<int> g_small_active{0};  // threads inside a small fit
 // Threads that have just come back from a small fit are the ones most likely to bring the next one: each thread keeps the time of
 // its last return in a slot of this table (0 while it is inside a fit), and the thread that opens a batch also waits for those
 // whose return is younger than HBEGP_SMALL_BATCH_RECENT_US (4 ms) -- without this, threads that finish together drift apart
@@ -1917,9 +1919,25 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   // (n_restarts = 0, or no more runs than devices): `extend` at the fitted theta then repeats the fit's own evaluation bit for bit
   SmallArrival arrival;  // other threads' small fits wait (briefly) for this one's runs before they launch: SmallBatcher
   if (small_fit) arrival.announce();
+  // The host-side phases of a small fit (set-up; model + release: ~35 runtime calls together) run one thread at a time: sixteen
+  // native threads that enter them at the same instant queue on the runtime's locks for 2-3 ms each, one after the other they take
+  // 0.1-0.2 ms (measured, n = 128, fits/s at 4 / 8 / 16 native threads: 312 / 507 / 865 -> 351 / 658 / 1,157; Python threads, which
+  // the interpreter lock staggers already: 1,198 -> 1,104 at 16).  Only while at most HBEGP_SMALL_HOST_SERIAL (16; 0 = never) threads
+  // are inside small fits: beyond that the turns themselves are the queue (24 threads: 1,031 without / 862 with; 32 threads on 16
+  // cores: 744 / 238), and a bounded wait for the turn (1-10 ms) keeps none of the gain (16 threads: 740-770).
+  static const int host_serial_max = env_int("HBEGP_SMALL_HOST_SERIAL", 16);
+  struct SmallActive {
+    bool on = false;
+    int enter() { on = true; return g_small_active.fetch_add(1) + 1; }
+    ~SmallActive() { if (on) g_small_active.fetch_sub(1); }
+  } small_active;
+  const bool host_serial = small_fit && small_active.enter() <= host_serial_max;
+  std::unique_lock<std::mutex> host_lk(g_small_host_mu, std::defer_lock);
+  if (host_serial) host_lk.lock();
   Problem<T> prob(ctx, X, y, n, d, nu, n_slots, false, true);
   const auto tf1 = std::chrono::steady_clock::now();
   if (!(small_fit && prob.small_)) arrival.arrived();
+  if (!(small_fit && prob.small_) && host_lk.owns_lock()) host_lk.unlock();
 
   std::vector<double> lnlo(p), lnhi(p);
   for (int i = 0; i < p; ++i) {
@@ -2005,6 +2023,11 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         HIPCHECK(hipSetDevice(ctx->devs[di]));
         // the grid runs on the batch's stream: what this fit queued on its own (features, observations, start points) is there first
         HIPCHECK(hipStreamSynchronize(prob.slots[di][0].stream));
+      }
+      if (host_lk.owns_lock()) host_lk.unlock();
+      for (int di = 0; di < ndev; ++di) {
+        if (fits_on[di].empty()) continue;
+        HIPCHECK(hipSetDevice(ctx->devs[di]));
         batches[di] = small_batch_submit<T>(ctx->devs[di], prob.nu2, fits_on[di], arrival);
       }
       // every run's word, in run order.  The stream is asked now and then: a grid that is over without the word (a fault) must not
@@ -2206,7 +2229,12 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   if (theta_best) memcpy(theta_best, th.data(), sizeof(double) * p);
   if (lml_best) *lml_best = best.best_lml;
   const auto tf2 = std::chrono::steady_clock::now();
+  if (host_serial && prob.small_ && !host_lk.owns_lock()) host_lk.lock();
   if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data());
+  if (host_lk.owns_lock()) {
+    prob.release();  // (again, harmlessly, when the problem goes out of scope)
+    host_lk.unlock();
+  }
   if (timing) {
     const auto tf3 = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

@@ -50,7 +50,9 @@
  *     the runs side by side and collects.  Same entry points, same contracts; HBEGP_SMALL=0 / HBEGP_SMALL_FIT=0 select the
  *     general path / the host-driven optimiser for comparison.  Such fits issued by several threads at the same time share
  *     their launches (one grid carries the runs of all fits that arrive within a few milliseconds of each other; a thread
- *     alone never waits): 16 threads reach ~1,100 fits/s at n = 128 where one reaches 95, each fit bit for bit its solo result.
+ *     alone never waits), and the host-side phases of such fits take turns while at most 16 threads are inside them (the HIP
+ *     runtime's locks do worse): 16 native threads reach ~1,140 fits/s at n = 128 where one reaches 95, each fit bit for bit its
+ *     solo result.
  */
 #ifndef HBEGP_H
 #define HBEGP_H
