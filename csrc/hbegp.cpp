@@ -1934,6 +1934,8 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   const bool host_serial = small_fit && small_active.enter() <= host_serial_max;
   std::unique_lock<std::mutex> host_lk(g_small_host_mu, std::defer_lock);
   if (host_serial) host_lk.lock();
+  const auto th0 = std::chrono::steady_clock::now();  // (HBEGP_TIMING: how long the turns are)
+  double held_ms = 0;
   Problem<T> prob(ctx, X, y, n, d, nu, n_slots, false, true);
   const auto tf1 = std::chrono::steady_clock::now();
   if (!(small_fit && prob.small_)) arrival.arrived();
@@ -2024,6 +2026,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         // the grid runs on the batch's stream: what this fit queued on its own (features, observations, start points) is there first
         HIPCHECK(hipStreamSynchronize(prob.slots[di][0].stream));
       }
+      held_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
       if (host_lk.owns_lock()) host_lk.unlock();
       for (int di = 0; di < ndev; ++di) {
         if (fits_on[di].empty()) continue;
@@ -2230,10 +2233,13 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
   if (lml_best) *lml_best = best.best_lml;
   const auto tf2 = std::chrono::steady_clock::now();
   if (host_serial && prob.small_ && !host_lk.owns_lock()) host_lk.lock();
+  const auto th1 = std::chrono::steady_clock::now();
   if (model_out) *model_out = make_model<T>(prob, (size_t)bdi, bsi, th.data(), best.best_lml, false, best.best_params.empty() ? nullptr : best.best_params.data());
   if (host_lk.owns_lock()) {
     prob.release();  // (again, harmlessly, when the problem goes out of scope)
+    held_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th1).count();
     host_lk.unlock();
+    if (timing) fprintf(stderr, "fit: host-side turns held for %.3f ms (set-up + model / release)\n", held_ms);
   }
   if (timing) {
     const auto tf3 = std::chrono::steady_clock::now();
