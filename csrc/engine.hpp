@@ -233,6 +233,8 @@ struct SmallFit {
   SmallEval ev;              // X, y, n, d, P (device workspace, written by the kernel), W2, ldiag, out = hout (device workspace)
   void* Kinv[2];
   void* alpha[2];
+  void* Xinv[2];             // L^-1 and diag(L) ping-pong with K^-1 and alpha (null: ev.W2 / ev.ldiag every time): the model is built
+  void* ldiag[2];            // from the captured evaluation's own factor instead of factoring once more at the captured theta
   LbfgsState* st;            // device workspace
   const double* x0;          // start point (log space), p = d + 2 entries
   const double* lo;          // linear-space box

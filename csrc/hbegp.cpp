@@ -594,6 +594,8 @@ template <typename T>
 struct Slot {
   int dev = 0;
   hipStream_t stream = nullptr;
+  T *Xalt = nullptr, *ldalt = nullptr;  // device-driven small fit: second buffers for L^-1 / diag(L) (they ping-pong with K^-1 / alpha)
+  bool x_captured = false;              // ... and after such a fit: (best_idx ? Xalt : W2) IS the captured evaluation's factor
   T *W1 = nullptr, *W2 = nullptr, *Kinv[2] = {nullptr, nullptr}, *alpha[2] = {nullptr, nullptr};
   T* W3 = nullptr;  // f32 problems only: the Cholesky factor L (lower), kept for the refinement of the panel solves
   T *ldiag = nullptr, *wbuf = nullptr;
@@ -1762,13 +1764,16 @@ static hbegp_model* make_model(Problem<T>& prob, size_t di, int si, const double
       theta_to_params(theta_clamped, nullptr, nullptr, prob.d, P);
     }
   };
-  if (!w2_current) {
+  // (x_captured: a device-driven small fit kept the captured evaluation's own factor: buffer b of the ping-pong pair)
+  const T* Xsrc = (s.x_captured && b == 1) ? s.Xalt : s.W2;
+  const T* ldsrc = (s.x_captured && b == 1) ? s.ldalt : s.ldiag;
+  if (!w2_current && !s.x_captured) {
     fill_params(s.hP);
     if (prob.factor_only(di, si) != HBEGP_OK) throw HipError{hipErrorUnknown, "factorisation at the captured theta failed", __LINE__};
   }
   m->ldiag = m->palloc(sizeof(T) * prob.np);
-  HIPCHECK(hipMemcpyAsync(m->ldiag, s.ldiag, sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
-  HIPCHECK(hipMemcpyAsync(m->Xinv, s.W2, sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
+  HIPCHECK(hipMemcpyAsync(m->ldiag, ldsrc, sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
+  HIPCHECK(hipMemcpyAsync(m->Xinv, Xsrc, sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->X, prob.Xd[di], sizeof(T) * (size_t)prob.n * prob.d, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->alpha, s.alpha[b], sizeof(T) * prob.np, hipMemcpyDeviceToDevice, m->stream));
   HIPCHECK(hipMemcpyAsync(m->Kinv, s.Kinv[b], sizeof(T) * nn, hipMemcpyDeviceToDevice, m->stream));
@@ -2011,6 +2016,18 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         f.ev.X = prob.Xd[w.di]; f.ev.y = prob.yd[w.di]; f.ev.n = n; f.ev.d = d; f.ev.P = s.dP;
         f.ev.W2 = s.W2; f.ev.ldiag = s.ldiag; f.ev.out = s.dOut; f.ev.hout = s.dOut;
         f.Kinv[0] = s.Kinv[0]; f.Kinv[1] = s.Kinv[1]; f.alpha[0] = s.alpha[0]; f.alpha[1] = s.alpha[1];
+        // L^-1 and diag(L) ping-pong too: the captured evaluation's factor survives the run, the model takes it as it is (no
+        // factorisation at the captured theta behind the fit: one small launch and a wait less inside the model's turn)
+        static const bool x_pingpong = env_int("HBEGP_SMALL_X_PINGPONG", 1) != 0;
+        if (x_pingpong) {
+          if (!s.Xalt) {
+            s.Xalt = prob.template palloc<T>(s.dev, (size_t)NB * NB);
+            s.ldalt = prob.template palloc<T>(s.dev, NB);
+            HIPCHECK(hipMemsetAsync(s.Xalt, 0, sizeof(T) * NB * NB, st));  // the strict upper triangle must be zero, like W2's
+          }
+          f.Xinv[0] = s.W2; f.Xinv[1] = s.Xalt; f.ldiag[0] = s.ldiag; f.ldiag[1] = s.ldalt;
+          s.x_captured = true;
+        }
         f.st = w.st; f.x0 = w.x0; f.lo = w.x0 + p; f.hi = w.x0 + 2 * p;
         LbfgsOptions lo_opt;
         f.maxeval = opt.maxeval; f.memory = opt.lbfgs_memory > 0 ? opt.lbfgs_memory : lo_opt.memory; f.fixed_work = opt.fixed_work != 0;

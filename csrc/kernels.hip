@@ -2639,6 +2639,10 @@ __global__ void __launch_bounds__(512, 2) small_fit_kernel(const SmallFit* __res
     SmallEval g = f.ev;
     g.Kinv = f.Kinv[target];
     g.alpha = f.alpha[target];
+    if (f.Xinv[target]) {
+      g.W2 = f.Xinv[target];
+      g.ldiag = f.ldiag[target];
+    }
     g.mode = 7;
     small_eval_call<TIO, NU2>(&g, smem_raw);
     __threadfence();
