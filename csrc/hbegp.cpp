@@ -786,8 +786,7 @@ struct Problem : ProblemBase {
           s.dP = reinterpret_cast<EvalParams*>(q); q += b_p;
           s.dOut = reinterpret_cast<EvalOut*>(q); q += b_o;
           s.tickets = reinterpret_cast<int*>(q);
-          HIPCHECK(hipMemsetAsync(s.dOut, 0, sizeof(EvalOut), st0));
-          HIPCHECK(hipMemsetAsync(s.tickets, 0, 256, st0));
+          HIPCHECK(hipMemsetAsync(s.dOut, 0, b_o + 256, st0));  // the result block and, right behind it, the tickets: one fill
           const size_t h_p = up(sizeof(EvalParams));
           s.host_slab_bytes = h_p + up(sizeof(EvalOut));
           s.host_slab = g_host_pool.get(s.host_slab_bytes);
@@ -1963,7 +1962,6 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
       LbfgsState* st = nullptr;
       SmallFitResult* res = nullptr;
       double *x0 = nullptr, *tr_theta = nullptr, *tr_lml = nullptr, *tr_grad = nullptr;
-      std::vector<double> box;  // start point, lower and upper bounds: the source of an asynchronous copy, kept until the run is collected
     };
     const int cap = opt.trace_cap > 0 ? opt.maxeval : 0;  // per run; the merged trace is cut at opt.trace_cap below
     std::vector<RunWs> ws(nruns);
@@ -1986,6 +1984,8 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
       // the runs of a device are the workgroups of ONE launch on the device's first slot stream (one stream per fit and device:
       // fits side by side on one GPU then do not queue behind each other's persistent kernels, see small_fit_kernel)
       std::vector<std::vector<SmallFit>> fits_on(ndev);
+      std::vector<double*> boxes_dev(ndev, nullptr);
+      std::vector<std::vector<double>> boxes_host(ndev);  // the source of an asynchronous copy: alive until the stream has been waited for below
       for (int r = 0; r < nruns; ++r) {
         RunWs& w = ws[r];
         w.di = r % ndev; w.si = next_slot[w.di]++; w.run = r;
@@ -1999,19 +1999,22 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
         char* base = reinterpret_cast<char*>(s.W1);
         w.st = reinterpret_cast<LbfgsState*>(base);
         w.res = reinterpret_cast<SmallFitResult*>(base + (sizeof(LbfgsState) + 15) / 16 * 16);
-        w.x0 = reinterpret_cast<double*>(reinterpret_cast<char*>(w.res) + (sizeof(SmallFitResult) + 15) / 16 * 16);
+        // start point and box of every run of a device: one array, one copy (a copy per run was a runtime call per run inside the turn)
+        if (!boxes_dev[w.di]) {
+          boxes_dev[w.di] = prob.template palloc<double>(s.dev, (size_t)runs_on[w.di] * 3 * p);
+          boxes_host[w.di].assign((size_t)runs_on[w.di] * 3 * p, 0.0);
+        }
+        w.x0 = boxes_dev[w.di] + (size_t)w.si * 3 * p;
         if (cap > 0) {
           w.tr_theta = prob.template palloc<double>(s.dev, (size_t)cap * p);
           w.tr_lml = prob.template palloc<double>(s.dev, cap);
           w.tr_grad = prob.template palloc<double>(s.dev, (size_t)cap * p);
         }
         const double* start = r == 0 ? theta0 : starts + (size_t)(r - 1) * p;
-        std::vector<double>& box = w.box;
-        box.assign(3 * (size_t)p, 0.0);  // start point, lower and upper bounds: one copy
-        memcpy(box.data(), start, sizeof(double) * p);
-        memcpy(box.data() + p, lo, sizeof(double) * p);
-        memcpy(box.data() + 2 * p, hi, sizeof(double) * p);
-        HIPCHECK(hipMemcpyAsync(w.x0, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice, st));
+        double* box = boxes_host[w.di].data() + (size_t)w.si * 3 * p;  // start point, lower and upper bounds
+        memcpy(box, start, sizeof(double) * p);
+        memcpy(box + p, lo, sizeof(double) * p);
+        memcpy(box + 2 * p, hi, sizeof(double) * p);
         SmallFit f{};
         f.ev.X = prob.Xd[w.di]; f.ev.y = prob.yd[w.di]; f.ev.n = n; f.ev.d = d; f.ev.P = s.dP;
         f.ev.W2 = s.W2; f.ev.ldiag = s.ldiag; f.ev.out = s.dOut; f.ev.hout = s.dOut;
@@ -2040,6 +2043,7 @@ static int do_fit(hbegp_ctx* ctx, const T* X, const T* y, int n, int d, double n
       for (int di = 0; di < ndev; ++di) {
         if (fits_on[di].empty()) continue;
         HIPCHECK(hipSetDevice(ctx->devs[di]));
+        HIPCHECK(hipMemcpyAsync(boxes_dev[di], boxes_host[di].data(), sizeof(double) * boxes_host[di].size(), hipMemcpyHostToDevice, prob.slots[di][0].stream));
         // the grid runs on the batch's stream: what this fit queued on its own (features, observations, start points) is there first
         HIPCHECK(hipStreamSynchronize(prob.slots[di][0].stream));
       }
