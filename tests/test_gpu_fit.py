@@ -522,3 +522,55 @@ def test_small_fits_of_different_shapes_share_launches_and_keep_their_bits():
             assert len(r) == len(solo[i])
             for a, b in zip(r, solo[i]):
                 assert np.array_equal(a, b), (i, shapes[i])
+
+
+@pytest.mark.parametrize("n", [90, 500, 900])
+def test_concurrent_extend_and_predict_reproduce_the_solo_results(n):
+    # include/hbegp.h, Threads: hbegp_extend_* and hbegp_predict_* are re-entrant per context as well -- six threads build models
+    # at different thetas side by side (LDS path, launch path, task queue) and predict from them, some sharing ONE model handle;
+    # every array equals the same call alone, bit for bit.
+    import threading
+
+    w = synth.make_workload("M", n=n)
+    X, y = w["X"], w["y"]
+    rng = np.random.default_rng(n)
+    thetas = [w["theta"] + 0.2 * rng.standard_normal(w["theta"].shape) for _ in range(3)]
+    Xs = synth.candidates("M", 40, w["d"])
+    ctx = gpr.Context(device_ids=[0])
+
+    def build(theta):
+        fk = gpr.FittedKernel.extend(X, y, theta, ctx=ctx)
+        alpha, kinv = fk.arrays()
+        mean, var, _ = fk.predict(Xs)
+        m1, v1, _ = fk.predict(Xs[:3])
+        out = (np.array([fk.lml]), alpha, kinv, mean, var, m1, v1)
+        return fk, out
+
+    solo = []
+    for th in thetas:
+        fk, out = build(th)
+        fk.release()
+        solo.append(out)
+    shared, shared_out = build(thetas[0])
+    errors, bad = [], []
+
+    def work(i):
+        try:
+            for rep in range(3):
+                fk, out = build(thetas[i % 3])
+                fk.release()
+                if not all(np.array_equal(a, b) for a, b in zip(out, solo[i % 3])):
+                    bad.append(("extend", i, rep))
+                mean, var, _ = shared.predict(Xs)  # one handle, many threads: the model serialises its own predictions
+                if not (np.array_equal(mean, shared_out[3]) and np.array_equal(var, shared_out[4])):
+                    bad.append(("shared predict", i, rep))
+        except Exception as e:  # noqa: BLE001 -- the assertion below reports it
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    shared.release()
+    ctx.close()
+    assert not errors, errors
+    assert not bad, bad
